@@ -1,0 +1,110 @@
+"""Weight container for the FCN-8 landmark model.
+
+The reference stores TF-checkpoint files written by Keras `ModelCheckpoint`
+(training.py:218-222); those cannot be parsed without TensorFlow and none ship
+with the reference.  This build's container is a flat ``.npz`` whose keys are
+``<layer>/<tensor>`` with tensors in the KERAS layouts (so a checkpoint exported
+from Keras with `layer.get_weights()` drops in unchanged):
+
+  enc{1..5}/kernel [3,3,Cin,F] HWIO   enc{i}/bias [F]
+  enc{i}/gamma|beta|moving_mean|moving_variance [F]     (BatchNormalization)
+  fc6/kernel [7,7,256,4096]  fc7/kernel [1,1,4096,4096]  + bias
+  score5/kernel [1,1,4096,C] score4/kernel [1,1,256,C] score3/kernel [1,1,256,C] + bias
+  up5/kernel [4,4,C,C] up4/kernel [4,4,C,C] up3/kernel [16,16,C,C]   (kh,kw,out,in), no bias
+
+No trained weights exist anywhere (reference README.md:4-7 lists the FCN detector
+as TODO), so benchmarks and tests use the seeded synthetic set below.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ENC_FILTERS = (64, 128, 256, 256, 256)  # networks/fcn.py:13,34,43
+FC_WIDTH = 4096                          # networks/fcn.py:98,100
+
+
+def fcn8_param_shapes(n_classes: int, channels: int = 3) -> dict:
+    shapes = {}
+    cin = channels
+    for i, f in enumerate(ENC_FILTERS, 1):
+        n = "enc%d" % i
+        shapes[n + "/kernel"] = (3, 3, cin, f)
+        for t in ("bias", "gamma", "beta", "moving_mean", "moving_variance"):
+            shapes[n + "/" + t] = (f,)
+        cin = f
+    shapes["fc6/kernel"] = (7, 7, cin, FC_WIDTH)
+    shapes["fc6/bias"] = (FC_WIDTH,)
+    shapes["fc7/kernel"] = (1, 1, FC_WIDTH, FC_WIDTH)
+    shapes["fc7/bias"] = (FC_WIDTH,)
+    shapes["score5/kernel"] = (1, 1, FC_WIDTH, n_classes)
+    shapes["score5/bias"] = (n_classes,)
+    shapes["score4/kernel"] = (1, 1, ENC_FILTERS[3], n_classes)
+    shapes["score4/bias"] = (n_classes,)
+    shapes["score3/kernel"] = (1, 1, ENC_FILTERS[2], n_classes)
+    shapes["score3/bias"] = (n_classes,)
+    shapes["up5/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up4/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up3/kernel"] = (16, 16, n_classes, n_classes)
+    return shapes
+
+
+def synth_fcn8_weights(n_classes: int = 68, seed: int = 2, channels: int = 3) -> dict:
+    """Seeded synthetic parameters.
+
+    Conv kernels ~ N(0, 2/fan_in) (he_normal, as networks/fcn.py:103,108,117 ask
+    for the score convs); biases ~ N(0, 0.01); BN gamma ~ U(0.5,1.5),
+    beta ~ N(0,0.1), mean ~ N(0,0.1), var ~ U(0.5,1.5).  The three score convs and
+    the transposed convs are scaled so the logits keep an O(1) spread (an
+    unsaturated softmax, so argmax / centroid are not degenerate).
+    """
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shp in fcn8_param_shapes(n_classes, channels).items():
+        layer, tensor = name.split("/")
+        if tensor == "kernel":
+            if layer.startswith("up"):
+                kh, kw, co, ci = shp
+                stride = 8 if layer == "up3" else 2
+                # each output pixel sums (kh/stride)*(kw/stride) taps of ci inputs
+                fan = (kh // stride) * (kw // stride) * ci
+                std = np.sqrt(1.0 / fan)
+            else:
+                kh, kw, ci, co = shp
+                std = np.sqrt(2.0 / (kh * kw * ci))
+            w = rng.standard_normal(shp, dtype=np.float32) * np.float32(std)
+            if layer == "enc1":
+                # inputs are mean-subtracted bytes (|x| up to ~130): keep enc1 O(1)
+                w *= np.float32(1.0 / 64.0)
+            p[name] = w
+        elif tensor == "bias":
+            p[name] = (rng.standard_normal(shp, dtype=np.float32) * np.float32(0.01))
+        elif tensor == "gamma":
+            p[name] = rng.uniform(0.5, 1.5, shp).astype(np.float32)
+        elif tensor == "beta":
+            p[name] = (rng.standard_normal(shp, dtype=np.float32) * np.float32(0.1))
+        elif tensor == "moving_mean":
+            p[name] = (rng.standard_normal(shp, dtype=np.float32) * np.float32(0.1))
+        elif tensor == "moving_variance":
+            p[name] = rng.uniform(0.5, 1.5, shp).astype(np.float32)
+        else:  # pragma: no cover
+            raise KeyError(name)
+    return p
+
+
+def save_weights(path: str, params: dict) -> None:
+    np.savez(path, **params)
+
+
+def load_weights_file(path: str) -> dict:
+    with np.load(path, allow_pickle=False) as z:
+        return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+
+
+def check_params(params: dict, n_classes: int, channels: int = 3) -> None:
+    want = fcn8_param_shapes(n_classes, channels)
+    missing = sorted(set(want) - set(params))
+    if missing:
+        raise KeyError("weight container lacks tensors: %s" % ", ".join(missing))
+    for k, shp in want.items():
+        if tuple(params[k].shape) != tuple(shp):
+            raise ValueError("tensor %s has shape %s, expected %s" % (k, tuple(params[k].shape), shp))

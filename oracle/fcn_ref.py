@@ -1,0 +1,159 @@
+"""CPU restatement of the reference's FCN-8 landmark forward.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference's arithmetic lives in TensorFlow/Keras (absent
+here, `requirements.txt` empty, nothing pinned) and the reference ships no tests
+or golden outputs.  Every function cites the reference lines it restates; Keras
+layer semantics are the documented library defaults:
+
+  Conv2D            cross-correlation, kernel HWIO (kh,kw,in,out), use_bias=True
+  ZeroPadding2D(1)  symmetric zero pad, applied AFTER preprocessing
+  BatchNormalization  last axis, epsilon=1e-3, inference uses moving statistics:
+                      gamma*(x-mean)/sqrt(var+eps)+beta
+  MaxPooling2D(2,2) stride 2, 'valid' (floor)
+  Dropout           identity at inference
+  Conv2DTranspose   kernel (kh,kw,out,in), 'valid', use_bias=False,
+                    out[s*i+a, s*j+b, o] += x[i,j,c]*w[a,b,o,c]; size (i-1)*s+k
+  Cropping2D(((t,b),(l,r)))  removes rows/cols from the named sides
+  softmax           last axis, max-subtracted
+
+Weights are passed as a dict of numpy arrays in Keras layouts:
+  enc{1..5}/{kernel,bias,gamma,beta,moving_mean,moving_variance}
+  fc6|fc7|score5|score4|score3 / {kernel,bias}
+  up5|up4|up3 / kernel
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3  # keras.layers.BatchNormalization default epsilon
+MEANS_BGR = (103.939, 116.779, 123.68)  # data/generator.py:56
+
+
+def get_image_array_ref(img_bgr_u8: np.ndarray) -> np.ndarray:
+    """`get_image_array(..., imgNorm="sub_mean", ordering="channels_last")`.
+
+    Follows data/generator.py:52-61 for an input already at (H, W): float32
+    cast, per-channel mean subtraction on BGR, then channel reversal (-> RGB).
+    The cv2.resize at :53 is the identity when the crop already has the model's
+    input size, which is the only case this oracle covers.
+    """
+    img = img_bgr_u8.astype(np.float32)
+    img = np.atleast_3d(img).copy()
+    for i in range(min(img.shape[2], 3)):
+        img[:, :, i] -= np.float32(MEANS_BGR[i])
+    return np.ascontiguousarray(img[:, :, ::-1])
+
+
+def _t(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+def _conv(x, w_hwio, b, pad, dtype):
+    # Keras HWIO -> torch OIHW; cross-correlation in both.
+    w = _t(w_hwio, dtype).permute(3, 2, 0, 1).contiguous()
+    return F.conv2d(x, w, None if b is None else _t(b, dtype), padding=pad)
+
+
+def _bn(x, p, name, dtype):
+    g = _t(p[name + "/gamma"], dtype)[None, :, None, None]
+    b = _t(p[name + "/beta"], dtype)[None, :, None, None]
+    m = _t(p[name + "/moving_mean"], dtype)[None, :, None, None]
+    v = _t(p[name + "/moving_variance"], dtype)[None, :, None, None]
+    return g * (x - m) / torch.sqrt(v + BN_EPS) + b
+
+
+def _convT(x, w_hwoi, stride, dtype):
+    # Keras (kh,kw,out,in) -> torch (in,out,kh,kw); both are scatter-add.
+    w = _t(w_hwoi, dtype).permute(3, 2, 0, 1).contiguous()
+    return F.conv_transpose2d(x, w, None, stride=stride)
+
+
+def vanilla_encoder_ref(x_nchw, p, dtype):
+    """networks/fcn.py:10-51: 5 x (ZeroPadding2D(1), Conv2D 3x3 valid, BN, ReLU, MaxPool 2x2)."""
+    levels = []
+    x = x_nchw
+    for i in range(1, 6):
+        n = "enc%d" % i
+        x = _conv(x, p[n + "/kernel"], p[n + "/bias"], 1, dtype)  # fcn.py:25-27 / 33-35 / 42-44
+        x = _bn(x, p, n, dtype)                                   # fcn.py:28 / 36 / 45
+        x = torch.relu(x)                                         # fcn.py:29 / 37 / 46
+        x = F.max_pool2d(x, 2, 2)                                 # fcn.py:30 / 38 / 47-48
+        levels.append(x)
+    return levels
+
+
+def crop_ref(o1, o2):
+    """networks/fcn.py:55-86.  The larger map loses its RIGHT columns and BOTTOM rows
+    (Cropping2D(((0,0),(0,cx))) then Cropping2D(((0,cy),(0,0)))): the top-left window stays."""
+    h1, w1 = o1.shape[2], o1.shape[3]
+    h2, w2 = o2.shape[2], o2.shape[3]
+    cx, cy = abs(w1 - w2), abs(h2 - h1)
+    if w1 > w2:
+        o1 = o1[:, :, :, : w1 - cx]
+    else:
+        o2 = o2[:, :, :, : w2 - cx]
+    if h1 > h2:
+        o1 = o1[:, :, : h1 - cy, :]
+    else:
+        o2 = o2[:, :, : h2 - cy, :]
+    return o1, o2
+
+
+def fcn8_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, return_intermediates=False):
+    """networks/fcn.py:89-122 up to (not including) the softmax.  x: [N,H,W,3] preprocessed."""
+    x = _t(x_nhwc, dtype).permute(0, 3, 1, 2).contiguous()
+    f1, f2, f3, f4, f5 = vanilla_encoder_ref(x, p, dtype)
+    o = torch.relu(_conv(f5, p["fc6/kernel"], p["fc6/bias"], 3, dtype))   # fcn.py:98 7x7 'same'; :99 dropout = id
+    fc6 = o
+    o = torch.relu(_conv(o, p["fc7/kernel"], p["fc7/bias"], 0, dtype))    # fcn.py:100-101
+    fc7 = o
+    o = _conv(o, p["score5/kernel"], p["score5/bias"], 0, dtype)          # fcn.py:103
+    o = _convT(o, p["up5/kernel"], 2, dtype)                              # fcn.py:104-105
+    o2 = _conv(f4, p["score4/kernel"], p["score4/bias"], 0, dtype)        # fcn.py:107-108
+    o, o2 = crop_ref(o, o2)                                               # fcn.py:110
+    o = o + o2                                                            # fcn.py:112
+    fuse4 = o
+    o = _convT(o, p["up4/kernel"], 2, dtype)                              # fcn.py:114-115
+    o2 = _conv(f3, p["score3/kernel"], p["score3/bias"], 0, dtype)        # fcn.py:116-117
+    o2, o = crop_ref(o2, o)                                               # fcn.py:118
+    o = o2 + o                                                            # fcn.py:119 "seg_feats"
+    seg = o
+    o = _convT(o, p["up3/kernel"], 8, dtype)                              # fcn.py:121-122
+    logits = o.permute(0, 2, 3, 1).contiguous()                           # NHWC
+    if return_intermediates:
+        nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().numpy()
+        return logits.numpy(), dict(f1=nhwc(f1), f2=nhwc(f2), f3=nhwc(f3), f4=nhwc(f4), f5=nhwc(f5),
+                                    fc6=nhwc(fc6), fc7=nhwc(fc7), fuse4=nhwc(fuse4), seg_feats=nhwc(seg))
+    return logits.numpy()
+
+
+def fcn8_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
+    """`model.predict` of the model built by fcn_8 + get_segmentation_model
+    (networks/utils.py:22-31): Reshape((H'*W', C)) then softmax over the last axis.
+    Returns [N, H'*W', C]."""
+    logits = torch.from_numpy(fcn8_logits_ref(x_nhwc, p, dtype))
+    n, h, w, c = logits.shape
+    pr = torch.softmax(logits.reshape(n, h * w, c), dim=-1)
+    return pr.numpy()
+
+
+def output_hw(input_h: int, input_w: int):
+    """Output grid of fcn_8 for an (input_h, input_w) input (multiples of 32):
+    enc -> /32; up5 (i-1)*2+4 cropped to /16; up4 cropped to /8; up3 (i-1)*8+16 = H+8."""
+    return input_h + 8, input_w + 8
+
+
+def class_map_ref(pr: np.ndarray, out_h: int, out_w: int, n_classes: int) -> np.ndarray:
+    """prediction.py:209: `pr.reshape((H', W', C)).argmax(axis=2)` (first maximum wins)."""
+    return pr.reshape((out_h, out_w, n_classes)).argmax(axis=2)
+
+
+def prediction_ref(img_bgr_u8: np.ndarray, p: dict, n_classes: int):
+    """`_prediction` up to the class map (prediction.py:207-209) for one crop
+    whose size already equals the model input size."""
+    x = get_image_array_ref(img_bgr_u8)
+    pr = fcn8_predict_ref(np.array([x]), p)[0]
+    oh, ow = output_hw(*img_bgr_u8.shape[:2])
+    return class_map_ref(pr, oh, ow, n_classes), pr
