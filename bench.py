@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the landmark hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic 256x256 uint8 BGR face crops
+already resident in HBM (BASELINE.json configs[1]: batch 64, fp32):
+    fused preprocess + FCN-8 forward -> softmax probabilities [64, 264*264, 68]
+    -> top-n landmark decode (n=4, thresh=0: the reference's as-shipped decode)
+    -> similarity fit + alignment warp to 256x256
+    -> (N > 1) RCCL all-gather of the landmark tensors.
+Ranks are weak-scaled: every rank runs its own batch (no data-path collective besides the
+landmark gather).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GFLOP_PER_FACE = 17.844          # 2*MAC over every Conv2D/Conv2DTranspose, dense
+FC6_GFLOP_PER_FACE = 6.5767      # fc6 7x7x256x4096 on 8x8, dense count (includes zero-padded taps)
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
+
+
+def cpu_baseline(n_faces, n_points, seed):
+    """The oracle (kind "port": the build's CPU restatement of prediction.py's path) timed on the
+    host cores: preprocess + FCN-8 forward + softmax + top-n decode for `n_faces` crops."""
+    import numpy as np
+    import torch
+    from flm_amd.weights import synth_fcn8_weights
+    from oracle import decode_ref, fcn_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = synth_fcn8_weights(68, seed=2)
+    rng = np.random.default_rng(seed)
+    crops = rng.integers(0, 256, (n_faces, 256, 256, 3), dtype=np.uint8)
+
+    def run(c):
+        x = np.stack([fcn_ref.get_image_array_ref(i) for i in c])
+        pr = fcn_ref.fcn8_predict_ref(x, params)
+        with np.errstate(all="ignore"):
+            return decode_ref.transfer_target_ref(pr.reshape(len(c), 264, 264, 68), 0, n_points)
+
+    run(crops[:1])  # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    lm = run(crops)
+    dt = time.perf_counter() - t0
+    return {"value": n_faces / dt, "unit": "faces/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic 256x256 crops through oracle/ (torch-CPU fp32 forward + numpy top-%d decode), "
+                      "%.1f s" % (n_faces, n_points, dt)}, lm, crops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="faces per GPU per step")
+    ap.add_argument("--n-points", type=int, default=4)
+    ap.add_argument("--cpu-faces", type=int, default=16, help="sample size of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-align", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import flm_amd  # noqa: F401
+    from flm_amd import _lib, alignment, distributed
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_fcn8_weights
+
+    rank, local_rank, world = distributed.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    if world > 1:
+        distributed.init_process_group("nccl")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.load()
+
+    B, H, W, CLS = args.batch, 256, 256, 68
+    model = LANDMARKS_MODELS["fcn_8"](CLS, input_height=H, input_width=W)
+    model.load_weights(synth_fcn8_weights(CLS, seed=2))
+    rng = np.random.default_rng(1 + rank)
+    crops = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(dev)
+    tmpl = torch.from_numpy(alignment.canonical_template(CLS, H, W)).to(dev)
+    scale = (model.input_width / model.output_width, model.input_height / model.output_height)
+    total = B * world
+
+    def step():
+        lm = model.forward_device(crops, "landmarks", n_points=args.n_points, thresh=0.0)
+        if not args.no_align:
+            aligned, m = alignment.align_device(crops, lm, tmpl, H, W, scale)
+        else:
+            aligned = None
+        full = distributed.all_gather_landmarks(lm, total) if world > 1 else lm
+        return full, aligned
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    n_layers = 16
+    _lib.check(lib.flm_profile_enable(args.steps * n_layers + 64), "flm_profile_enable")
+    lib.flm_profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full, aligned = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-launch durations recorded by HIP events inside the timed region -----------------------
+    layer_ms = {}
+    name = C.create_string_buffer(32)
+    ms = C.c_float()
+    i = 0
+    while lib.flm_profile_read(i, name, 32, C.byref(ms)) == 0:
+        layer_ms.setdefault(name.value.decode(), []).append(ms.value)
+        i += 1
+    lib.flm_profile_disable()
+    layer_avg = {k: float(np.mean(v)) for k, v in layer_ms.items()}
+
+    if rank == 0:
+        value = total * args.steps / dt
+        fwd_keys = [k for k in layer_avg if k != "decode"]
+        fwd_ms = sum(layer_avg[k] for k in fwd_keys)
+        fc6_ms = layer_avg.get("fc6", float("nan"))
+        fc6_tflops = FC6_GFLOP_PER_FACE * B / fc6_ms  # GFLOP / ms = TFLOP/s
+        fwd_tflops = GFLOP_PER_FACE * B / fwd_ms
+        rec = {
+            "metric": "faces/sec (whole node), 256x256 batch inference: fused preprocess + FCN-8 forward + "
+                      "softmax + top-%d landmark decode + similarity/alignment warp" % args.n_points,
+            "value": value, "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=%d/GPU 256x256x3 uint8 crops, fcn_8(68) vanilla "
+                                   "encoder fp32, random-init weights (seed 2), decode top-%d thresh 0, "
+                                   "align to 256x256%s" % (B, args.n_points, "" if not args.no_align else " (off)"),
+                       "faces_per_gpu_per_step": B, "parallelism": "dp%d" % world,
+                       "collective": "all_gather landmarks [B,68,2] f64" if world > 1 else "none"},
+            "roofline": {"bound": "mfma",
+                         "kernel": "igemm_f32_kernel<MMAP=2,RELU> (fc6: 7x7x256->4096 on 8x8, M=64*B, K=12544)",
+                         "achieved": fc6_tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fc6_tflops / PEAK_F32_TFLOPS, "traffic": None,
+                         "flop_per_launch": FC6_GFLOP_PER_FACE * 1e9 * B, "avg_launch_ms": fc6_ms},
+            "forward": {"gflop_per_face": GFLOP_PER_FACE, "ms": fwd_ms, "tflops": fwd_tflops,
+                        "frac_of_f32_mfma_peak": fwd_tflops / PEAK_F32_TFLOPS,
+                        "faces_per_s_forward_only": 1e3 * B / fwd_ms, "layer_ms": layer_avg},
+        }
+        if args.cpu_faces > 0:
+            base, lm_cpu, crops_cpu = cpu_baseline(args.cpu_faces, args.n_points, seed=1)
+            rec["cpu_baseline"] = base
+            # the same crops on the GPU: landmark NME vs the oracle (NME := mean ||p - p_ref|| / 256)
+            nb = min(args.cpu_faces, B)
+            xd = torch.from_numpy(crops_cpu[:nb]).to(dev)
+            got = model.forward_device(xd, "landmarks", n_points=args.n_points).cpu().numpy()
+            ref = lm_cpu[:nb].reshape(nb, CLS, 2)
+            err = np.linalg.norm(got - ref, axis=-1)
+            rec["parity"] = {"landmark_nme_vs_oracle": float(err.mean() / 256.0),
+                             "max_coord_err_px": float(np.abs(got - ref).max()), "faces": nb}
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,404 @@
+// extern "C" entry points of libflm_hip.so (see include/flm.h) and the forward's launch sequence.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "flm_common.h"
+
+namespace flm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return FLM_ERR_HIP;
+}
+
+// ---- optional per-launch timing (bench.py): hipEvent pairs around every launch of the forward --------
+// Off by default; when enabled the forward records two events per layer on the caller's stream and
+// never synchronises -- flm_profile_read() does, after the caller's own timed region has ended.
+struct ProfRec {
+  const char* name;
+  hipEvent_t a, b;
+};
+static ProfRec* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+
+struct ProfScope {
+  hipStream_t s;
+  ProfRec* r;
+  ProfScope(hipStream_t st, const char* name) : s(st), r(nullptr) {
+    if (g_prof && g_prof_n < g_prof_cap) {
+      r = &g_prof[g_prof_n++];
+      r->name = name;
+      (void)hipEventRecord(r->a, s);
+    }
+  }
+  ~ProfScope() {
+    if (r) (void)hipEventRecord(r->b, s);
+  }
+};
+
+static size_t take(size_t& cur, size_t bytes) {
+  size_t o = cur;
+  cur = align_up(cur + bytes, 256);
+  return o;
+}
+
+Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int out_mode, int decode_mode, int n_points) {
+  Fcn8Ws W;
+  const ConvTGeom g = convt_geom(C);
+  size_t cur = 0;
+  int hh = h, ww = w;
+  for (int i = 0; i < 5; ++i) {
+    hh >>= 1;
+    ww >>= 1;
+    W.f[i] = take(cur, sizeof(float) * (size_t)n * hh * ww * kEncF[i]);
+  }
+  const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
+  W.fc6 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * kFc);
+  W.fc7 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * kFc);
+  W.score5 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * g.Cp);
+  W.fuse4 = take(cur, sizeof(float) * (size_t)n * h4 * w4 * g.Cp);
+  W.seg = take(cur, sizeof(float) * (size_t)n * h3 * w3 * g.Cp);
+  W.oh = h + 8;
+  W.ow = w + 8;
+  W.probs = SIZE_MAX;
+  W.decode = SIZE_MAX;
+  if (out_mode == FLM_OUT_LANDMARKS) {
+    W.probs = take(cur, sizeof(float) * (size_t)n * W.oh * W.ow * C);
+    W.decode = take(cur, decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
+  }
+  W.total = cur;
+  return W;
+}
+
+static int check_fcn8_shape(int n, int h, int w, int C, int dtype) {
+  if (dtype != FLM_F32) {
+    set_error("fcn8: dtype %d is not built in this library (fp32 only)", dtype);
+    return FLM_ERR_UNSUPPORTED;
+  }
+  if (n <= 0 || h <= 0 || w <= 0 || (h % 32) || (w % 32)) {
+    set_error("fcn8: input must be [N>0, H, W, 3] with H and W multiples of 32 (got n=%d h=%d w=%d)", n, h, w);
+    return FLM_ERR_SHAPE;
+  }
+  if (C < 1 || C > kMaxClasses) {
+    set_error("fcn8: n_classes must be in [1,%d] (got %d)", kMaxClasses, C);
+    return FLM_ERR_SHAPE;
+  }
+  if ((long long)n * (h + 8) * (w + 8) * C >= (1ll << 40)) {
+    set_error("fcn8: batch too large");
+    return FLM_ERR_SHAPE;
+  }
+  return FLM_OK;
+}
+
+static int conv_layer(hipStream_t s, const char* blob, const ConvPack& c, const float* x, float* y, int n, int h,
+                      int w, int relu, int pool, int posmajor) {
+  IgemmDesc d;
+  d.x = x;
+  d.wt = reinterpret_cast<const float*>(blob + c.w);
+  d.scale = reinterpret_cast<const float*>(blob + c.scale);
+  d.shift = reinterpret_cast<const float*>(blob + c.shift);
+  d.y = y;
+  d.n = n; d.h = h; d.w = w; d.cin = c.cin;
+  d.cout = c.cout; d.coutpad = c.coutpad; d.ldc = c.cout;
+  d.kh = c.kh; d.kw = c.kw; d.pad = c.pad;
+  d.relu = relu; d.pool = pool; d.posmajor = posmajor;
+  return launch_igemm_f32(s, d);
+}
+
+}  // namespace flm
+
+using namespace flm;
+
+extern "C" {
+
+int flm_abi_version(void) { return FLM_ABI_VERSION; }
+
+int flm_profile_enable(int max_records) {
+  if (g_prof) return FLM_OK;
+  if (max_records <= 0 || max_records > (1 << 20)) {
+    set_error("flm_profile_enable: bad record count");
+    return FLM_ERR_ARG;
+  }
+  g_prof = new ProfRec[max_records];
+  for (int i = 0; i < max_records; ++i) {
+    FLM_HIP(hipEventCreate(&g_prof[i].a));
+    FLM_HIP(hipEventCreate(&g_prof[i].b));
+  }
+  g_prof_cap = max_records;
+  g_prof_n = 0;
+  return FLM_OK;
+}
+
+int flm_profile_reset(void) {
+  g_prof_n = 0;
+  return FLM_OK;
+}
+
+int flm_profile_read(int index, char* name_out, int name_cap, float* ms_out) {
+  if (!g_prof || index < 0 || index >= g_prof_n) return 1;  // past the end
+  ProfRec& r = g_prof[index];
+  FLM_HIP(hipEventSynchronize(r.b));
+  FLM_HIP(hipEventElapsedTime(ms_out, r.a, r.b));
+  if (name_out && name_cap > 0) {
+    strncpy(name_out, r.name, name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  return FLM_OK;
+}
+
+int flm_profile_disable(void) {
+  if (!g_prof) return FLM_OK;
+  for (int i = 0; i < g_prof_cap; ++i) {
+    (void)hipEventDestroy(g_prof[i].a);
+    (void)hipEventDestroy(g_prof[i].b);
+  }
+  delete[] g_prof;
+  g_prof = nullptr;
+  g_prof_cap = g_prof_n = 0;
+  return FLM_OK;
+}
+const char* flm_last_error(void) { return g_err; }
+
+size_t flm_fcn8_packed_bytes(int n_classes, int dtype) {
+  if (dtype != FLM_F32 || n_classes < 1 || n_classes > kMaxClasses) return 0;
+  return fcn8_pack_layout(n_classes).total;
+}
+
+int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
+                  size_t packed_bytes) {
+  if (!p || !packed_dev) {
+    set_error("flm_fcn8_pack: null argument");
+    return FLM_ERR_ARG;
+  }
+  if (dtype != FLM_F32) {
+    set_error("flm_fcn8_pack: dtype %d not built (fp32 only)", dtype);
+    return FLM_ERR_UNSUPPORTED;
+  }
+  if (n_classes < 1 || n_classes > kMaxClasses) {
+    set_error("flm_fcn8_pack: n_classes must be in [1,%d]", kMaxClasses);
+    return FLM_ERR_SHAPE;
+  }
+  const Fcn8Pack L = fcn8_pack_layout(n_classes);
+  if (packed_bytes < L.total) {
+    set_error("flm_fcn8_pack: packed buffer too small (%zu < %zu)", packed_bytes, L.total);
+    return FLM_ERR_WORKSPACE;
+  }
+  return launch_pack_fcn8(static_cast<hipStream_t>(stream), *p, n_classes, L, static_cast<char*>(packed_dev));
+}
+
+size_t flm_fcn8_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                                int n_points) {
+  if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
+  return fcn8_ws_layout(n, h, w, n_classes, out_mode, decode_mode, n_points).total;
+}
+
+int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype, int out_mode,
+                                  int decode_mode, int n_points) {
+  if (!name || check_fcn8_shape(n, h, w, n_classes, dtype)) return -1;
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, n_classes, out_mode, decode_mode, n_points);
+  if (name[0] == 'f' && name[1] >= '1' && name[1] <= '5' && name[2] == 0) return (int64_t)W.f[name[1] - '1'];
+  if (!strcmp(name, "fc6")) return (int64_t)W.fc6;
+  if (!strcmp(name, "fc7")) return (int64_t)W.fc7;
+  if (!strcmp(name, "score5")) return (int64_t)W.score5;
+  if (!strcmp(name, "fuse4")) return (int64_t)W.fuse4;
+  if (!strcmp(name, "seg_feats")) return (int64_t)W.seg;
+  if (!strcmp(name, "probs")) return W.probs == SIZE_MAX ? -1 : (int64_t)W.probs;
+  return -1;
+}
+
+int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
+                     int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
+                     void* out_dev, void* workspace_dev, size_t workspace_bytes) {
+  if (!packed_dev || !x_dev || !out_dev || !workspace_dev) {
+    set_error("flm_fcn8_forward: null argument");
+    return FLM_ERR_ARG;
+  }
+  int rc = check_fcn8_shape(n, h, w, C, dtype);
+  if (rc) return rc;
+  if (out_mode < FLM_OUT_PROBS || out_mode > FLM_OUT_LOGITS) {
+    set_error("flm_fcn8_forward: unknown output mode %d", out_mode);
+    return FLM_ERR_ARG;
+  }
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, out_mode, decode_mode, n_points);
+  if (workspace_bytes < W.total) {
+    set_error("flm_fcn8_forward: workspace too small (%zu < %zu)", workspace_bytes, W.total);
+    return FLM_ERR_WORKSPACE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Fcn8Pack L = fcn8_pack_layout(C);
+  const char* blob = static_cast<const char*>(packed_dev);
+  char* ws = static_cast<char*>(workspace_dev);
+  float* f[5];
+  for (int i = 0; i < 5; ++i) f[i] = reinterpret_cast<float*>(ws + W.f[i]);
+  float* fc6 = reinterpret_cast<float*>(ws + W.fc6);
+  float* fc7 = reinterpret_cast<float*>(ws + W.fc7);
+  float* score5 = reinterpret_cast<float*>(ws + W.score5);
+  float* fuse4 = reinterpret_cast<float*>(ws + W.fuse4);
+  float* seg = reinterpret_cast<float*>(ws + W.seg);
+
+  // encoder (networks/fcn.py:10-51)
+  { ProfScope ps(s, "enc1");
+  rc = launch_enc1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
+                   reinterpret_cast<const float*>(blob + L.enc1_scale),
+                   reinterpret_cast<const float*>(blob + L.enc1_shift), f[0]); }
+  if (rc) return rc;
+  int hh = h / 2, ww = w / 2;
+  for (int i = 0; i < 4; ++i) {
+    static const char* const enc_names[4] = {"enc2", "enc3", "enc4", "enc5"};
+    { ProfScope ps(s, enc_names[i]);
+    rc = conv_layer(s, blob, L.enc[i], f[i], f[i + 1], n, hh, ww, /*relu*/ 1, /*pool*/ 1, 0); }
+    if (rc) return rc;
+    hh /= 2;
+    ww /= 2;
+  }
+  const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
+  // head (fcn.py:98-103); Dropout is the identity at inference
+  { ProfScope ps(s, "fc6");
+  rc = conv_layer(s, blob, L.fc6, f[4], fc6, n, h5, w5, 1, 0, /*posmajor*/ 1); }
+  if (rc) return rc;
+  { ProfScope ps(s, "fc7");
+  rc = conv_layer(s, blob, L.fc7, fc6, fc7, n, h5, w5, 1, 0, 0); }
+  if (rc) return rc;
+  { ProfScope ps(s, "score5");
+  rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0); }
+  if (rc) return rc;
+  // skip branches: score4 on f4 -> fuse4 buffer, score3 on f3 -> seg buffer, then the transposed
+  // convs add themselves onto those (crop keeps the top-left window, fcn.py:76-84)
+  { ProfScope ps(s, "score4");
+  rc = conv_layer(s, blob, L.score4, f[3], fuse4, n, h4, w4, 0, 0, 0); }
+  if (rc) return rc;
+  { ProfScope ps(s, "score3");
+  rc = conv_layer(s, blob, L.score3, f[2], seg, n, h3, w3, 0, 0, 0); }
+  if (rc) return rc;
+  ConvTDesc t;
+  t.g = L.g;
+  t.n = n;
+  // up5 (fcn.py:104) + crop + Add (fcn.py:110-112), in place on fuse4
+  t.x = score5; t.wf = reinterpret_cast<const float*>(blob + L.up5); t.skip = fuse4; t.y = fuse4;
+  t.hi = h5; t.wi = w5; t.ho = h4; t.wo = w4; t.s = 2; t.ldy = L.g.Cp; t.epilogue = 0;
+  { ProfScope ps(s, "up5");
+  rc = launch_convt(s, t); }
+  if (rc) return rc;
+  // up4 (fcn.py:114) + crop + Add (fcn.py:118-119), in place on seg ("seg_feats")
+  t.x = fuse4; t.wf = reinterpret_cast<const float*>(blob + L.up4); t.skip = seg; t.y = seg;
+  t.hi = h4; t.wi = w4; t.ho = h3; t.wo = w3;
+  { ProfScope ps(s, "up4");
+  rc = launch_convt(s, t); }
+  if (rc) return rc;
+  // up3 (fcn.py:121) + softmax (networks/utils.py:30) / argmax (prediction.py:209)
+  t.x = seg; t.wf = reinterpret_cast<const float*>(blob + L.up3); t.skip = nullptr;
+  t.hi = h3; t.wi = w3; t.ho = W.oh; t.wo = W.ow; t.s = 8; t.ldy = C;
+  if (out_mode == FLM_OUT_LOGITS || out_mode == FLM_OUT_PROBS) {
+    t.y = out_dev;
+    t.epilogue = (out_mode == FLM_OUT_PROBS) ? 1 : 0;
+    if (out_mode == FLM_OUT_LOGITS && (C & 3)) {
+      set_error("flm_fcn8_forward: FLM_OUT_LOGITS needs n_classes %% 4 == 0");
+      return FLM_ERR_UNSUPPORTED;
+    }
+    ProfScope ps(s, "up3");
+    return launch_convt(s, t);
+  }
+  if (out_mode == FLM_OUT_CLASSMAP) {
+    t.y = out_dev;
+    t.epilogue = 2;
+    ProfScope ps(s, "up3");
+    return launch_convt(s, t);
+  }
+  // landmarks: probs to the workspace, then the decode (utils/metrics.py:102-109)
+  float* probs = reinterpret_cast<float*>(ws + W.probs);
+  t.y = probs;
+  t.epilogue = 1;
+  { ProfScope ps(s, "up3");
+  rc = launch_convt(s, t); }
+  if (rc) return rc;
+  ProfScope ps(s, "decode");
+  return launch_decode(s, probs, n, W.oh, W.ow, C, C, decode_mode, n_points, thresh,
+                       static_cast<double*>(out_dev), ws + W.decode,
+                       decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
+}
+
+int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const float* x_dev,
+                       float* y_dev, int n, int h, int w, int C, int dtype) {
+  if (!packed_dev || !layer || !x_dev || !y_dev || n <= 0 || h <= 0 || w <= 0) {
+    set_error("flm_fcn8_run_layer: bad argument");
+    return FLM_ERR_ARG;
+  }
+  if (dtype != FLM_F32 || C < 1 || C > kMaxClasses) {
+    set_error("flm_fcn8_run_layer: unsupported dtype/n_classes");
+    return FLM_ERR_UNSUPPORTED;
+  }
+  const Fcn8Pack L = fcn8_pack_layout(C);
+  const char* blob = static_cast<const char*>(packed_dev);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!strncmp(layer, "enc", 3) && layer[3] >= '2' && layer[3] <= '5' && layer[4] == 0)
+    return conv_layer(s, blob, L.enc[layer[3] - '2'], x_dev, y_dev, n, h, w, 1, 1, 0);
+  if (!strcmp(layer, "fc6")) return conv_layer(s, blob, L.fc6, x_dev, y_dev, n, h, w, 1, 0, 1);
+  if (!strcmp(layer, "fc7")) return conv_layer(s, blob, L.fc7, x_dev, y_dev, n, h, w, 1, 0, 0);
+  if (!strcmp(layer, "score5")) return conv_layer(s, blob, L.score5, x_dev, y_dev, n, h, w, 0, 0, 0);
+  if (!strcmp(layer, "score4")) return conv_layer(s, blob, L.score4, x_dev, y_dev, n, h, w, 0, 0, 0);
+  if (!strcmp(layer, "score3")) return conv_layer(s, blob, L.score3, x_dev, y_dev, n, h, w, 0, 0, 0);
+  set_error("flm_fcn8_run_layer: unknown layer '%s'", layer);
+  return FLM_ERR_ARG;
+}
+
+int flm_preprocess(flm_stream_t stream, const uint8_t* img, int n, int h, int w, int norm, float* out) {
+  if (!img || !out || n <= 0 || h <= 0 || w <= 0) {
+    set_error("flm_preprocess: bad argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_preprocess(static_cast<hipStream_t>(stream), img, n, h, w, norm, out);
+}
+
+size_t flm_decode_workspace_bytes(int n, int h, int w, int l, int mode, int n_points) {
+  if (n <= 0 || h <= 0 || w <= 0 || l <= 0) return 0;
+  return decode_ws_bytes(n, h, w, l, mode, n_points);
+}
+
+int flm_decode(flm_stream_t stream, const float* hm, int n, int h, int w, int l, int mode, int n_points,
+               float thresh, double* out, void* ws, size_t ws_bytes) {
+  if (!hm || !out || !ws) {
+    set_error("flm_decode: null argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_decode(static_cast<hipStream_t>(stream), hm, n, h, w, l, l, mode, n_points, thresh, out, ws,
+                       ws_bytes);
+}
+
+int flm_similarity_from_landmarks(flm_stream_t stream, const double* lm, const double* tmpl, int n, int k,
+                                  float* m) {
+  if (!lm || !tmpl || !m) {
+    set_error("flm_similarity_from_landmarks: null argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_similarity(static_cast<hipStream_t>(stream), lm, tmpl, n, k, m);
+}
+
+int flm_warp_affine(flm_stream_t stream, const void* src, int src_is_u8, int n, int hs, int ws, const float* m,
+                    float* dst, int hd, int wd) {
+  if (!src || !m || !dst) {
+    set_error("flm_warp_affine: null argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_warp(static_cast<hipStream_t>(stream), src, src_is_u8, n, hs, ws, m, dst, hd, wd);
+}
+
+int flm_crop_resize(flm_stream_t stream, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,
+                    uint8_t* out, int oh, int ow) {
+  if (!frame || !boxes || !out) {
+    set_error("flm_crop_resize: null argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_crop_resize(static_cast<hipStream_t>(stream), frame, fh, fw, boxes, k, out, oh, ow);
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Shared declarations of libflm_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "flm.h"
+
+namespace flm {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define FLM_HIP(call)                                            \
+  do {                                                           \
+    hipError_t e_ = (call);                                      \
+    if (e_ != hipSuccess) return ::flm::hip_fail(e_, #call);     \
+  } while (0)
+
+#define FLM_LAUNCH_CHECK(what)                                   \
+  do {                                                           \
+    hipError_t e_ = hipGetLastError();                           \
+    if (e_ != hipSuccess) return ::flm::hip_fail(e_, what);      \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+constexpr float kBnEps = 1e-3f;  // keras BatchNormalization default epsilon
+
+// ---- architecture constants (networks/fcn.py:13,34,43,98,100) ------------------------------
+constexpr int kEncF[5] = {64, 128, 256, 256, 256};
+constexpr int kFc = 4096;
+constexpr int kMaxClasses = 96;
+
+// Geometry of the transposed-conv kernels for a class count C.
+struct ConvTGeom {
+  int C;   // classes
+  int Cp;  // channel stride of the score / fuse buffers (multiple of 4)
+  int MT;  // 16-row class tiles
+  int G;   // 16-deep k groups over K = 4 taps * Cp
+};
+ConvTGeom convt_geom(int C);
+
+// One implicit-GEMM conv layer inside the packed blob (offsets in bytes).
+struct ConvPack {
+  size_t w;      // float [coutpad][kh*kw*cin], k = (ky*kw+kx)*cin + c
+  size_t scale;  // float [coutpad]
+  size_t shift;  // float [coutpad]
+  int cin, cout, coutpad, kh, kw, pad;
+};
+
+struct Fcn8Pack {
+  size_t enc1_w;  // float [64][32], k = ky*9+kx*3+c (c in RGB order), zero for k >= 27
+  size_t enc1_scale, enc1_shift;
+  ConvPack enc[4];  // enc2..enc5
+  ConvPack fc6, fc7, score5, score4, score3;
+  size_t up5, up4, up3;  // float [s*s phases][G][MT][64 lanes][4]
+  ConvTGeom g;
+  size_t total;
+};
+Fcn8Pack fcn8_pack_layout(int C);
+
+// Workspace of the forward (offsets in bytes).
+struct Fcn8Ws {
+  size_t f[5];
+  size_t fc6, fc7, score5, fuse4, seg;
+  size_t probs;   // logits/probs when they are not the call's output (else == SIZE_MAX)
+  size_t decode;  // decode partials
+  size_t total;
+  int oh, ow;
+};
+Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int out_mode, int decode_mode, int n_points);
+
+// ---- kernel launchers (each returns FLM_OK or an error) --------------------------------------
+int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8Pack& L, char* blob);
+
+int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
+                const float* scale, const float* shift, float* f1);
+
+struct IgemmDesc {
+  const float* x;      // [n,h,w,cin]
+  const float* wt;     // [coutpad][K]
+  const float* scale;  // [coutpad]
+  const float* shift;  // [coutpad]
+  float* y;            // [n,ho,wo,ldc]  (ho,wo = h,w or h/2,w/2 when pooled)
+  int n, h, w, cin;
+  int cout;     // columns stored
+  int coutpad;  // rows of wt (multiple of 128)
+  int ldc;      // channel stride of y
+  int kh, kw, pad;
+  int relu, pool, posmajor;
+};
+int launch_igemm_f32(hipStream_t s, const IgemmDesc& d);
+
+struct ConvTDesc {
+  const float* x;     // [n,hi,wi,Cp]
+  const float* wf;    // fragment-packed weights
+  const float* skip;  // [n,ho,wo,Cp] added to the result, or null
+  void* y;            // logits/probs float [n,ho,wo,ldy] or int32 class map [n,ho,wo]
+  int n, hi, wi;      // input grid
+  int ho, wo;         // output grid after the crop (<= s*(hi+1))
+  int s;              // stride; kernel = 2s
+  int ldy;            // channel stride of y (C for the final layer, Cp for score buffers)
+  int epilogue;       // 0 raw (+skip), 1 softmax probs, 2 argmax class map
+  ConvTGeom g;
+};
+int launch_convt(hipStream_t s, const ConvTDesc& d);
+
+size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points);
+int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,
+                  float thresh, double* out, void* ws, size_t ws_bytes);
+
+int launch_preprocess(hipStream_t s, const uint8_t* img, int n, int h, int w, int norm, float* out);
+int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, float* m);
+int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, int ws, const float* m, float* dst,
+                int hd, int wd);
+int launch_crop_resize(hipStream_t s, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,
+                       uint8_t* out, int oh, int ow);
+
+// Bijective XCD-aware remap of a 1-D grid: blocks that the dispatcher deals to the same XCD
+// (b % 8) receive consecutive logical ids, so neighbours in logical order share an L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = b & 7, loc = b >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
+
+}  // namespace flm

@@ -1,0 +1,272 @@
+// Transposed convolutions of the FCN-8 decoder, exact fp32 on the matrix cores
+// (v_mfma_f32_16x16x4_f32), with the crop/add and the per-pixel softmax / argmax fused.
+//
+//   up5  Conv2DTranspose(C, 4x4, stride 2, valid, no bias)   networks/fcn.py:104-105
+//        + crop to the skip map (keeps the top-left window)   fcn.py:55-86,110
+//        + Add(score4)                                        fcn.py:112
+//   up4  same, + Add(score3)                                  fcn.py:114-119
+//   up3  Conv2DTranspose(C, 16x16, stride 8)                  fcn.py:121-122
+//        + Reshape + softmax over classes                     networks/utils.py:28-30
+//        (+ argmax over classes                               prediction.py:209)
+//
+// Kernel size = 2 * stride in all three, so in gather form every output pixel
+// (s*i0+a0, s*j0+b0) sums exactly 2x2 input pixels (i0-di, j0-dj) with filter taps
+// (a0+s*di, b0+s*dj): per phase (a0,b0) a GEMM  D[class][pixel] = W_phase[class][k] * X[k][pixel],
+// k = (di,dj,c), K = 4*Cp.
+//
+// Classes sit on the MFMA ROW index, pixels on the lane: all classes of a pixel are then 4*MT
+// registers of 4 lanes (lane, lane+16, +32, +48), so softmax/argmax over classes is an in-lane
+// reduction plus two xor-shuffles.  One workgroup = 64 input positions (16 per wave) x one phase
+// row a0 x all b0: each wave keeps its X fragments in registers for all phases (68 VGPRs at C=68)
+// and streams the phase's weights, pre-packed in fragment order, through a double-buffered LDS
+// ring (lane-linear ds_read_b128, conflict-free by construction).  For a fixed a0 consecutive b0
+// write 8 consecutive output pixels = one 2176-byte run at C=68.
+#include "flm_common.h"
+
+namespace flm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvTArgs {
+  const float* x;
+  const float* wf;
+  const float* skip;
+  void* y;
+  int n, hi, wi, ho, wo, s, ldy, epilogue;
+  int C, Cp;
+  int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
+};
+
+constexpr int GCH = 6;  // k groups per LDS chunk
+
+template <int MT, int G>
+__global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
+  constexpr int NCH = (G + GCH - 1) / GCH;
+  constexpr int CHUNK_F4 = GCH * MT * 64;             // float4 per full chunk
+  constexpr int NLD = (CHUNK_F4 + 255) / 256;         // staging loads per thread
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float4* lds = reinterpret_cast<float4*>(smem_raw);  // [2][CHUNK_F4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int a0 = blockIdx.y;
+  const int s = a.s;
+
+  // ---- this lane's input position ---------------------------------------------------------------
+  const int p = blockIdx.x * 64 + wave * 16 + r;
+  const bool pvalid = p < a.P;
+  const int pp = pvalid ? p : 0;
+  const int wi1 = a.wi + 1, hi1 = a.hi + 1;
+  const int j0 = pp % wi1, i0 = (pp / wi1) % hi1, img = pp / (wi1 * hi1);
+
+  // ---- X fragments: xf[g] = x[tap(k4)][c(k4)..+3], k4 = 16g + 4q --------------------------------
+  float4 xf[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k4 = 16 * g + 4 * q;
+    const int tap = k4 / a.Cp, c = k4 % a.Cp;
+    const int ii = i0 - (tap >> 1), jj = j0 - (tap & 1);
+    const bool ok = pvalid && tap < 4 && (unsigned)ii < (unsigned)a.hi && (unsigned)jj < (unsigned)a.wi;
+    const size_t off = ok ? (((size_t)img * a.hi + ii) * a.wi + jj) * a.Cp + c : 0;
+    const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+    xf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- weight stream: (b0, chunk) sequence for this phase row ------------------------------------
+  const size_t phase_f4 = (size_t)G * MT * 64;
+  const float4* wbase = reinterpret_cast<const float4*>(a.wf) + (size_t)a0 * s * phase_f4;
+  const int total = s * NCH;
+  float4 st[NLD];
+  auto issue = [&](int seq) {
+    const int b0 = seq / NCH, ch = seq % NCH;
+    const int ng = (G - ch * GCH) < GCH ? (G - ch * GCH) : GCH;
+    const int cnt = ng * MT * 64;
+    const float4* src = wbase + (size_t)b0 * phase_f4 + (size_t)ch * CHUNK_F4;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      st[i] = src[idx < cnt ? idx : 0];
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < CHUNK_F4) lds[buf * CHUNK_F4 + idx] = st[i];
+    }
+  };
+
+  issue(0);
+  stash(0);
+  __syncthreads();
+
+  int seq = 0;
+  for (int b0 = 0; b0 < s; ++b0) {
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const bool more = seq + 1 < total;
+      if (more) issue(seq + 1);
+      const float4* wl = lds + (seq & 1) * CHUNK_F4;
+#pragma unroll
+      for (int gl = 0; gl < GCH; ++gl) {
+        const int g = ch * GCH + gl;  // compile-time
+        if (g < G) {
+          float4 af[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) af[m] = wl[(gl * MT + m) * 64 + lane];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[g].x, acc[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[g].y, acc[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[g].z, acc[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[g].w, acc[m], 0, 0, 0);
+        }
+      }
+      if (more) stash((seq + 1) & 1);
+      __syncthreads();
+      ++seq;
+    }
+
+    // ---- epilogue for output pixel (s*i0+a0, s*j0+b0): lane holds classes 16m + 4q + e ------------
+    const int oy = s * i0 + a0, ox = s * j0 + b0;
+    const bool ovalid = pvalid && oy < a.ho && ox < a.wo;
+    const size_t opix = ((size_t)img * a.ho + oy) * a.wo + ox;
+    if (a.epilogue == 0) {
+      if (ovalid) {
+        float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int c4 = 16 * m + 4 * q;
+          if (c4 < a.ldy) {  // ldy is a multiple of 4 here (score buffers, Cp channels)
+            float4 v = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            if (a.skip) {
+              const float4 sk = *reinterpret_cast<const float4*>(a.skip + opix * a.Cp + c4);
+              v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
+            }
+            *reinterpret_cast<float4*>(y + c4) = v;
+          }
+        }
+      }
+    } else {
+      // softmax over the C classes of this pixel (networks/utils.py:30), max-subtracted
+      float mx = -3.402823466e38f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (16 * m + 4 * q + e < a.C) mx = fmaxf(mx, acc[m][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ex = (16 * m + 4 * q + e < a.C) ? expf(acc[m][e] - mx) : 0.f;
+          acc[m][e] = ex;
+          sum += ex;
+        }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][e] = acc[m][e] / sum;
+      if (a.epilogue == 1) {
+        if (ovalid) {
+          float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;
+          if ((a.ldy & 3) == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const int c4 = 16 * m + 4 * q;
+              if (c4 < a.C) *reinterpret_cast<float4*>(y + c4) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            }
+          } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int c = 16 * m + 4 * q + e;
+                if (c < a.C) y[c] = acc[m][e];
+              }
+          }
+        }
+      } else {
+        // argmax over classes, first maximum wins (numpy argmax, prediction.py:209)
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = 16 * m + 4 * q + e;  // ascending within a lane
+            if (c < a.C && acc[m][e] > bv) {
+              bv = acc[m][e];
+              bi = c;
+            }
+          }
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+          const float ov = __shfl_xor(bv, sh);
+          const int oi = __shfl_xor(bi, sh);
+          if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        if (ovalid && q == 0) reinterpret_cast<int*>(a.y)[opix] = bi;
+      }
+    }
+  }
+}
+
+template <int MT, int G>
+static int launch_t(hipStream_t st, const ConvTArgs& a) {
+  constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid(cdiv(a.P, 64), a.s);
+  convt_kernel<MT, G><<<grid, 256, lds, st>>>(a);
+  FLM_LAUNCH_CHECK("convt_kernel");
+  return FLM_OK;
+}
+
+int launch_convt(hipStream_t st, const ConvTDesc& d) {
+  ConvTArgs a;
+  a.x = d.x; a.wf = d.wf; a.skip = d.skip; a.y = d.y;
+  a.n = d.n; a.hi = d.hi; a.wi = d.wi; a.ho = d.ho; a.wo = d.wo; a.s = d.s; a.ldy = d.ldy;
+  a.epilogue = d.epilogue; a.C = d.g.C; a.Cp = d.g.Cp;
+  const long long P = (long long)d.n * (d.hi + 1) * (d.wi + 1);
+  if (P <= 0 || P > (1ll << 30) || d.ho > d.s * (d.hi + 1) || d.wo > d.s * (d.wi + 1)) {
+    set_error("convt: bad geometry n=%d in=%dx%d out=%dx%d s=%d", d.n, d.hi, d.wi, d.ho, d.wo, d.s);
+    return FLM_ERR_SHAPE;
+  }
+  a.P = (int)P;
+  if (d.epilogue == 0 && (d.ldy & 3)) {
+    set_error("convt: raw epilogue needs a channel stride that is a multiple of 4");
+    return FLM_ERR_SHAPE;
+  }
+  if (d.g.C == 68 && d.g.G == 17) return launch_t<5, 17>(st, a);
+  switch (d.g.MT) {
+    case 1: return launch_t<1, 4>(st, a);
+    case 2: return launch_t<2, 8>(st, a);
+    case 3: return launch_t<3, 12>(st, a);
+    case 4: return launch_t<4, 16>(st, a);
+    case 5: return launch_t<5, 20>(st, a);
+    case 6: return launch_t<6, 24>(st, a);
+  }
+  set_error("convt: n_classes %d not supported (max %d)", d.g.C, kMaxClasses);
+  return FLM_ERR_SHAPE;
+}
+
+}  // namespace flm

@@ -1,0 +1,301 @@
+// Heatmap -> landmark coordinates ("soft-argmax"), HBM-bound single pass over the heatmaps.
+//
+// Restates get_average_xy / transfer_xy_coord / transfer_target (reference utils/metrics.py:46-109):
+//   n_points < 1 : full-map weighted centroid                                  (:58-64)
+//   n_points >= 1: weighted centroid of the n largest pixels                   (:66-77)
+//   reject -> (-1,-1) when  hsum / n_points <= thresh                          (:78-79)
+// Numeric types follow the reference's numpy behaviour: in the top-n branch `hsum` is a sequential
+// float32 sum in ascending value order and the index-weighted sums are float64; the coordinates are
+// float64.  Ties at the n-th place: pixels are ordered by (value, flat index), the n largest kept.
+//
+// Pass 1 (decode_partial): grid = (chunks, faces).  A workgroup streams its pixel range in tiles of
+// 64 pixels x L channels: coalesced 16-byte loads -> LDS (row stride odd, so a wave reading one
+// channel of 64 pixels is bank-conflict-free) -> each wave owns L/4 channels with lane = pixel.
+//   ALL : per-lane float64 partial sums in registers, one wave reduction at the end.
+//   TOPN: per channel a descending list of the n best (value,index) keys spread over the wave's
+//         lanes (lane i = i-th best); a 64-pixel batch is tested against the list's n-th key with one
+//         compare + ballot, insertions (rare after warm-up) are a ballot/popcount + one lane shift.
+// Pass 2 (decode_merge): one wave per (face, landmark) merges the chunk partials and finishes the
+// arithmetic in the reference's order.
+#include "flm_common.h"
+
+namespace flm {
+
+constexpr int PT = 64;  // pixels per tile
+
+struct DecodeArgs {
+  const float* hm;
+  int n, h, w, l;
+  int chunks, chunk_px;  // chunk_px multiple of 64
+  int mode, n_points;
+  int vec;  // face stride is a multiple of 16 bytes: 16-byte loads allowed
+  float thresh;
+  void* part;   // ALL: double [n][chunks][l][3]; TOPN: u64 [n][chunks][l][64]
+  double* out;  // [n][l][2]
+};
+
+__device__ __forceinline__ unsigned order_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float from_order_bits(unsigned o) {
+  const unsigned u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int srclane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, srclane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), srclane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int lane) {
+  const unsigned lo = __shfl_up((unsigned)v, 1);
+  const unsigned hi = __shfl_up((unsigned)(v >> 32), 1);
+  return lane == 0 ? 0ull : (((unsigned long long)hi << 32) | lo);
+}
+
+// Insert every key of `cand` (one per lane, 0 = none) that beats the list's n-th entry.
+// list: descending across lanes 0..n-1 (0 = empty slot); tau = list[n-1].
+__device__ __forceinline__ void insert_candidates(unsigned long long& list, unsigned long long& tau,
+                                                  unsigned long long cand, int n, int lane) {
+  unsigned long long mask = __ballot(cand > tau);
+  while (mask) {
+    const int src = __builtin_ctzll(mask);
+    const unsigned long long k = readlane64(cand, src);
+    if (lane == src) cand = 0;
+    const int pos = __builtin_popcountll(__ballot(list > k));  // entries that stay ahead of k
+    const unsigned long long up = shfl_up64(list, lane);
+    list = (lane < pos) ? list : (lane == pos ? k : up);
+    if (lane >= n) list = 0;
+    tau = readlane64(list, n - 1);
+    mask = __ballot(cand > tau);
+  }
+}
+
+template <int MODE, int CPW>
+__global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [PT][LS]
+  const int L = a.l, LS = L | 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int face = blockIdx.y, chunk = blockIdx.x;
+  const int HW = a.h * a.w;
+  const int p_begin = chunk * a.chunk_px;
+  const int p_end = min(p_begin + a.chunk_px, HW);
+  const float* src = a.hm + (size_t)face * HW * L;
+  const int c_first = wave * CPW;
+
+  double s0[CPW], sx[CPW], sy[CPW];                 // ALL
+  unsigned long long list[CPW], tau[CPW];           // TOPN
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    if (MODE == FLM_DECODE_ALL) {
+      s0[i] = 0.0; sx[i] = 0.0; sy[i] = 0.0;
+    } else {
+      list[i] = 0ull; tau[i] = 0ull;
+    }
+  }
+
+  const int tile_f = PT * L;  // floats per full tile (multiple of 4 because PT is)
+  for (int p0 = p_begin; p0 < p_end; p0 += PT) {
+    const int npx = min(PT, p_end - p0);
+    const int nf = npx * L;
+    __syncthreads();
+    // ---- stage: 16-byte coalesced loads, scatter into the odd-stride LDS image -------------------
+    const float* tsrc = src + (size_t)p0 * L;
+    for (int e4 = tid * 4; e4 < tile_f; e4 += 256 * 4) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.vec && e4 + 3 < nf) {
+        const float4 t = *reinterpret_cast<const float4*>(tsrc + e4);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (e4 + i < nf) v[i] = tsrc[e4 + i];
+      }
+      int p = e4 / L, c = e4 - p * L;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (e4 + i < tile_f) tile[p * LS + c] = v[i];
+        if (++c == L) { c = 0; ++p; }
+      }
+    }
+    __syncthreads();
+
+    const int pix = p0 + lane;
+    const bool pvalid = lane < npx;
+    if (MODE == FLM_DECODE_ALL) {
+      const double dx = (double)(pix % a.w), dy = (double)(pix / a.w);
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        const int c = c_first + i;
+        if (c < L) {
+          const double hv = pvalid ? (double)tile[lane * LS + c] : 0.0;
+          s0[i] += hv;
+          sx[i] = fma(hv, dx, sx[i]);
+          sy[i] = fma(hv, dy, sy[i]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        const int c = c_first + i;
+        if (c < L) {  // wave-uniform
+          const float hv = tile[lane * LS + c];
+          const unsigned long long key =
+              pvalid ? (((unsigned long long)order_bits(hv) << 32) | (unsigned)pix) : 0ull;
+          if (__any(key > tau[i])) insert_candidates(list[i], tau[i], key, a.n_points, lane);
+        }
+      }
+    }
+  }
+
+  // ---- write partials ---------------------------------------------------------------------------
+  if (MODE == FLM_DECODE_ALL) {
+    double* part = reinterpret_cast<double*>(a.part) + ((size_t)face * a.chunks + chunk) * L * 3;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = c_first + i;
+      if (c < L) {
+        double v0 = s0[i], v1 = sx[i], v2 = sy[i];
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {  // fixed-order butterfly: deterministic
+          v0 += __shfl_xor(v0, sh);
+          v1 += __shfl_xor(v1, sh);
+          v2 += __shfl_xor(v2, sh);
+        }
+        if (lane == 0) {
+          part[c * 3 + 0] = v0;
+          part[c * 3 + 1] = v1;
+          part[c * 3 + 2] = v2;
+        }
+      }
+    }
+  } else {
+    unsigned long long* part =
+        reinterpret_cast<unsigned long long*>(a.part) + ((size_t)face * a.chunks + chunk) * L * 64;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = c_first + i;
+      if (c < L) part[(size_t)c * 64 + lane] = list[i];
+    }
+  }
+}
+
+// one wave per (face, landmark)
+template <int MODE>
+__global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x, face = blockIdx.y;
+  const int L = a.l;
+  double* out = a.out + ((size_t)face * L + c) * 2;
+  if (MODE == FLM_DECODE_ALL) {
+    if (lane != 0) return;
+    const double* part = reinterpret_cast<const double*>(a.part) + (size_t)face * a.chunks * L * 3;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (int s = 0; s < a.chunks; ++s) {
+      v0 += part[((size_t)s * L + c) * 3 + 0];
+      v1 += part[((size_t)s * L + c) * 3 + 1];
+      v2 += part[((size_t)s * L + c) * 3 + 2];
+    }
+    // utils/metrics.py:60: hsum is float32 (np.sum of a float32 map), n_points = H*W
+    const float hsum = (float)v0;
+    double x = v1 / (double)hsum, y = v2 / (double)hsum;
+    if (hsum / (float)(a.h * a.w) <= a.thresh) { x = -1.0; y = -1.0; }
+    out[0] = x;
+    out[1] = y;
+  } else {
+    const unsigned long long* part =
+        reinterpret_cast<const unsigned long long*>(a.part) + (size_t)face * a.chunks * L * 64;
+    unsigned long long list = 0ull, tau = 0ull;
+    for (int s = 0; s < a.chunks; ++s) {
+      const unsigned long long cand = part[((size_t)s * L + c) * 64 + lane];
+      if (__any(cand > tau)) insert_candidates(list, tau, cand, a.n_points, lane);
+    }
+    // utils/metrics.py:69-77: ascending value order = list lanes n-1 .. 0
+    float hsum = 0.f;
+    double i0 = 0.0, i1 = 0.0;
+    for (int i = a.n_points - 1; i >= 0; --i) {
+      const unsigned long long k = readlane64(list, i);
+      if (k == 0ull) continue;
+      const float hv = from_order_bits((unsigned)(k >> 32));
+      const unsigned idx = (unsigned)k;
+      hsum += hv;
+      i0 += (double)(idx / (unsigned)a.w) * (double)hv;
+      i1 += (double)(idx % (unsigned)a.w) * (double)hv;
+    }
+    double x = i1 / (double)hsum, y = i0 / (double)hsum;
+    if (hsum / (float)a.n_points <= a.thresh) { x = -1.0; y = -1.0; }
+    if (lane == 0) {
+      out[0] = x;
+      out[1] = y;
+    }
+  }
+}
+
+static void decode_plan(int n, int h, int w, int* chunks, int* chunk_px) {
+  const int HW = h * w;
+  int s = 2048 / (n > 0 ? n : 1);
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  int px = (HW + s - 1) / s;
+  px = (px + PT - 1) / PT * PT;
+  *chunk_px = px;
+  *chunks = (HW + px - 1) / px;
+}
+
+size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points) {
+  int chunks, chunk_px;
+  decode_plan(n, h, w, &chunks, &chunk_px);
+  const size_t per = (mode == FLM_DECODE_ALL) ? sizeof(double) * 3 : sizeof(unsigned long long) * 64;
+  return align_up((size_t)n * chunks * l * per, 256);
+}
+
+int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,
+                  float thresh, double* out, void* ws, size_t ws_bytes) {
+  if (n <= 0 || h <= 0 || w <= 0 || l <= 0 || l > kMaxClasses || ld != l) {
+    set_error("decode: unsupported shape n=%d h=%d w=%d l=%d (max %d landmarks)", n, h, w, l, kMaxClasses);
+    return FLM_ERR_SHAPE;
+  }
+  if ((long long)h * w >= (1ll << 31)) {
+    set_error("decode: map too large");
+    return FLM_ERR_SHAPE;
+  }
+  if (mode == FLM_DECODE_TOPN && (n_points < 1 || n_points > 64)) {
+    set_error("decode: top-n mode supports 1 <= n_points <= 64 (got %d)", n_points);
+    return FLM_ERR_UNSUPPORTED;
+  }
+  if (mode != FLM_DECODE_ALL && mode != FLM_DECODE_TOPN) {
+    set_error("decode: unknown mode %d", mode);
+    return FLM_ERR_ARG;
+  }
+  if (reinterpret_cast<uintptr_t>(hm) & 15) {
+    set_error("decode: heatmap pointer must be 16-byte aligned");
+    return FLM_ERR_ARG;
+  }
+  if (ws_bytes < decode_ws_bytes(n, h, w, l, mode, n_points)) {
+    set_error("decode: workspace too small");
+    return FLM_ERR_WORKSPACE;
+  }
+  DecodeArgs a;
+  a.hm = hm; a.n = n; a.h = h; a.w = w; a.l = l;
+  decode_plan(n, h, w, &a.chunks, &a.chunk_px);
+  a.mode = mode; a.n_points = n_points; a.thresh = thresh; a.part = ws; a.out = out;
+  a.vec = (((long long)h * w * l) & 3) == 0;
+  const size_t lds = sizeof(float) * PT * (l | 1);
+  dim3 grid(a.chunks, n);
+  const bool small = l <= 68;  // 17 channels per wave
+  if (mode == FLM_DECODE_ALL) {
+    if (small) decode_partial_kernel<FLM_DECODE_ALL, 17><<<grid, 256, lds, s>>>(a);
+    else decode_partial_kernel<FLM_DECODE_ALL, 24><<<grid, 256, lds, s>>>(a);
+    FLM_LAUNCH_CHECK("decode_partial_kernel");
+    decode_merge_kernel<FLM_DECODE_ALL><<<dim3(l, n), 64, 0, s>>>(a);
+  } else {
+    if (small) decode_partial_kernel<FLM_DECODE_TOPN, 17><<<grid, 256, lds, s>>>(a);
+    else decode_partial_kernel<FLM_DECODE_TOPN, 24><<<grid, 256, lds, s>>>(a);
+    FLM_LAUNCH_CHECK("decode_partial_kernel");
+    decode_merge_kernel<FLM_DECODE_TOPN><<<dim3(l, n), 64, 0, s>>>(a);
+  }
+  FLM_LAUNCH_CHECK("decode_merge_kernel");
+  return FLM_OK;
+}
+
+}  // namespace flm

@@ -1,0 +1,287 @@
+// Implicit-GEMM convolution, exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Covers every Conv2D of the reference's fcn_8 + vanilla_encoder except enc1
+// (networks/fcn.py:33-48 enc2..5 with ZeroPadding2D(1)+BN+ReLU+MaxPool fused; :98 fc6 7x7 'same';
+// :100 fc7; :103,108,117 score convs).
+//
+//   C[m][o] = sum_k A[m][k] * Wt[o][k]      m = output pixel, k = (ky,kx,c), o = output channel
+//
+// Tile: 128 pixels x 128 channels per 256-thread workgroup, BK = 32 (one 128-byte run of input
+// channels of one filter tap, so the im2col gather is a row of 16-byte loads).  4 waves as 2x2,
+// each 64x64 = 2x2 MFMA tiles of 32x32.  Operands are staged global -> registers -> LDS with the
+// next k-step's loads in flight under the current step's 64 MFMAs; LDS rows are 128 B with the
+// 16-byte chunk index XOR-swizzled by (row>>1)&7 so ds_read_b128 by 32 consecutive rows is
+// conflict-free.  K is consumed in a permuted order (lane half h of MFMA step s of group t reads
+// k = 8t+4h+s) applied identically to both operands, so one ds_read_b128 feeds four MFMAs.
+//
+// Pixel order along M (template MMAP):
+//   0  row-major (n, y, x)
+//   1  2x2 quads (n, y/2, x/2, y&1, x&1): the four rows of a max-pool window are registers
+//      4j..4j+3 of one lane in the 32x32 accumulator layout, so the pool is an in-lane max and
+//      the pooled pixel index is m>>2.
+//   2  position-major (y, x, n): a tile holds one or two spatial positions of many faces, so
+//      filter taps that fall outside the 8x8 map for the whole tile are skipped (fc6: 7x7 'same'
+//      on 8x8 -- 38 % of its dense MACs multiply zero padding).
+#include "flm_common.h"
+
+namespace flm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IgemmArgs {
+  const float* x;
+  const float* wt;
+  const float* scale;
+  const float* shift;
+  float* y;
+  int n, h, w, cin;
+  int cout, ldc;
+  int kh, kw, pad;
+  int M;        // n*h*w
+  int K;        // kh*kw*cin
+  int mtiles, ntiles;
+  int cpt;      // 32-channel chunks per tap = cin/32
+};
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_F = BM * BK;  // floats per operand tile
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int MMAP, bool RELU>
+__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);  // [2][TILE_F]
+  float* Bs = As + 2 * TILE_F;                     // [2][TILE_F]
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(Bs + 2 * TILE_F);  // [4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = L % a.mtiles, nt = L / a.mtiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- staging role: rows r0+32j, 16-byte chunk c8 of the 128-byte k-run ----------------------
+  const int c8 = tid & 7, r0 = tid >> 3;
+  int pn[4], py[4], px[4];
+  bool pv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 32 * j;
+    pv[j] = m < a.M;
+    const int mm = pv[j] ? m : 0;
+    if (MMAP == 0) {
+      px[j] = mm % a.w;
+      py[j] = (mm / a.w) % a.h;
+      pn[j] = mm / (a.w * a.h);
+    } else if (MMAP == 1) {
+      const int q = mm >> 2, d = mm & 3, wp = a.w >> 1, hp = a.h >> 1;
+      px[j] = 2 * (q % wp) + (d & 1);
+      py[j] = 2 * ((q / wp) % hp) + (d >> 1);
+      pn[j] = q / (wp * hp);
+    } else {
+      pn[j] = mm % a.n;
+      const int pos = mm / a.n;
+      py[j] = pos / a.w;
+      px[j] = pos % a.w;
+    }
+  }
+
+  // ---- which filter taps touch at least one in-bounds pixel of this tile ------------------------
+  const int ntaps = a.kh * a.kw;
+  unsigned long long tapmask;
+  if (ntaps == 1) {
+    tapmask = 1ull;
+  } else {
+    unsigned long long mymask = 0;
+    for (int t = 0; t < ntaps; ++t) {
+      const int ky = t / a.kw - a.pad, kx = t % a.kw - a.pad;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        any |= pv[j] && (unsigned)(py[j] + ky) < (unsigned)a.h && (unsigned)(px[j] + kx) < (unsigned)a.w;
+      if (__any(any)) mymask |= 1ull << t;
+    }
+    if (lane == 0) s_mask[wave] = mymask;
+    __syncthreads();
+    tapmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    tapmask = __builtin_amdgcn_readfirstlane((unsigned)tapmask) |
+              ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(tapmask >> 32)) << 32);
+  }
+  const int nit = __builtin_popcountll(tapmask) * a.cpt;
+
+  float4 ra[4], rb[4];
+  bool ok[4];
+
+  // iterator over (valid tap, channel chunk)
+  unsigned long long rem = tapmask;
+  int cur_tap = __builtin_ctzll(rem);
+  int cur_chunk = 0;
+
+  auto issue_loads = [&]() {
+    const int ky = cur_tap / a.kw - a.pad, kx = cur_tap % a.kw - a.pad;
+    const int koff = cur_tap * a.cin + cur_chunk * BK + 4 * c8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = py[j] + ky, ix = px[j] + kx;
+      ok[j] = pv[j] && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+      // out-of-bounds rows load a valid address (pixel 0 of the tensor) and are zeroed at the LDS write,
+      // so the loads issue back to back with no branch around them
+      const size_t pix = ok[j] ? ((size_t)(pn[j] * a.h + iy) * a.w + ix) : 0;
+      ra[j] = *reinterpret_cast<const float4*>(a.x + pix * a.cin + cur_chunk * BK + 4 * c8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      rb[j] = *reinterpret_cast<const float4*>(a.wt + (size_t)(n0 + r0 + 32 * j) * a.K + koff);
+    // advance
+    if (++cur_chunk == a.cpt) {
+      cur_chunk = 0;
+      rem &= rem - 1;
+      cur_tap = rem ? __builtin_ctzll(rem) : 0;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = r0 + 32 * j;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(As + buf * TILE_F + swz(row, c8)) = ok[j] ? ra[j] : z;
+      *reinterpret_cast<float4*>(Bs + buf * TILE_F + swz(row, c8)) = rb[j];
+    }
+  };
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nit > 0) {
+    issue_loads();
+    store_lds(0);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < nit;
+    if (more) issue_loads();
+    const float* Ab = As + buf * TILE_F;
+    const float* Bb = Bs + buf * TILE_F;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const float4*>(Ab + swz(64 * wr + 32 * i + lr, 2 * t + lh));
+        bf[i] = *reinterpret_cast<const float4*>(Bb + swz(64 * wc + 32 * i + lr, 2 * t + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: y = acc*scale + shift, ReLU, 2x2 max-pool (MMAP 1), store ---------------------
+  // accumulator layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + 64 * wc + 32 * j + lr;
+    const bool cok = col < a.cout;
+    const float sc = a.scale[col], sh = a.shift[col];  // coutpad-long arrays: always in bounds
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mbase = m0 + 64 * wr + 32 * i;
+      if (MMAP == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = -3.402823466e38f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = fmaf(acc[i][j][4 * g + e], sc, sh);
+            if (RELU) u = fmaxf(u, 0.f);
+            v = fmaxf(v, u);
+          }
+          const int m = mbase + 8 * g + 4 * lh;  // first row of the quad
+          if (cok && m < a.M) a.y[(size_t)(m >> 2) * a.ldc + col] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float u = fmaf(acc[i][j][r], sc, sh);
+          if (RELU) u = fmaxf(u, 0.f);
+          if (cok && m < a.M) {
+            size_t orow;
+            if (MMAP == 2) {
+              const int nn = m % a.n, pos = m / a.n;
+              orow = (size_t)nn * (a.h * a.w) + pos;
+            } else {
+              orow = (size_t)m;
+            }
+            a.y[orow * a.ldc + col] = u;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MMAP, bool RELU>
+static int launch_t(hipStream_t s, const IgemmArgs& a) {
+  const size_t lds = sizeof(float) * 4 * TILE_F + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<MMAP, RELU>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  igemm_f32_kernel<MMAP, RELU><<<a.mtiles * a.ntiles, 256, lds, s>>>(a);
+  FLM_LAUNCH_CHECK("igemm_f32_kernel");
+  return FLM_OK;
+}
+
+int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
+  if (d.cin % 32 != 0 || d.coutpad % BN != 0 || d.cout > d.coutpad || d.kh * d.kw > 64) {
+    set_error("igemm_f32: unsupported shape cin=%d coutpad=%d cout=%d k=%dx%d", d.cin, d.coutpad, d.cout, d.kh, d.kw);
+    return FLM_ERR_SHAPE;
+  }
+  if (d.pool && ((d.h & 1) || (d.w & 1))) {
+    set_error("igemm_f32: pooled layer needs even h,w (got %dx%d)", d.h, d.w);
+    return FLM_ERR_SHAPE;
+  }
+  const long long M = (long long)d.n * d.h * d.w;
+  if (M <= 0 || M > (1ll << 30)) {
+    set_error("igemm_f32: pixel count %lld out of range", M);
+    return FLM_ERR_SHAPE;
+  }
+  IgemmArgs a;
+  a.x = d.x; a.wt = d.wt; a.scale = d.scale; a.shift = d.shift; a.y = d.y;
+  a.n = d.n; a.h = d.h; a.w = d.w; a.cin = d.cin; a.cout = d.cout; a.ldc = d.ldc;
+  a.kh = d.kh; a.kw = d.kw; a.pad = d.pad;
+  a.M = (int)M;
+  a.K = d.kh * d.kw * d.cin;
+  a.mtiles = cdiv(a.M, BM);
+  a.ntiles = d.coutpad / BN;
+  a.cpt = d.cin / BK;
+  // only whole N tiles that hold stored columns are launched
+  a.ntiles = cdiv(d.cout, BN);
+  if (d.pool) return d.relu ? launch_t<1, true>(s, a) : launch_t<1, false>(s, a);
+  if (d.posmajor) return d.relu ? launch_t<2, true>(s, a) : launch_t<2, false>(s, a);
+  return d.relu ? launch_t<0, true>(s, a) : launch_t<0, false>(s, a);
+}
+
+}  // namespace flm

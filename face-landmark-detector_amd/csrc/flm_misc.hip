@@ -1,0 +1,216 @@
+// Bandwidth-bound helpers around the forward: standalone preprocess, similarity estimate,
+// alignment warp, crop front-end.
+#include "flm_common.h"
+
+namespace flm {
+
+// ---- get_image_array (reference data/generator.py:29-69) for crops already at model size ------------
+//   sub_mean        float32(u8) - [103.939,116.779,123.68] per BGR channel, then channel reversal (:52-61)
+//   sub_and_divide  float32(u8)/127.5 - 1   (:50-51, no channel reversal)
+//   divide          float32(u8)/255         (:62-65, no channel reversal)
+__global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, size_t npix, int norm) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    const float b = (float)img[3 * i + 0], g = (float)img[3 * i + 1], r = (float)img[3 * i + 2];
+    float o0, o1, o2;
+    if (norm == FLM_NORM_SUB_MEAN) {
+      o0 = r - 123.68f;
+      o1 = g - 116.779f;
+      o2 = b - 103.939f;
+    } else if (norm == FLM_NORM_SUB_AND_DIVIDE) {
+      o0 = b / 127.5f - 1.f;
+      o1 = g / 127.5f - 1.f;
+      o2 = r / 127.5f - 1.f;
+    } else {
+      o0 = b / 255.0f;
+      o1 = g / 255.0f;
+      o2 = r / 255.0f;
+    }
+    out[3 * i + 0] = o0;
+    out[3 * i + 1] = o1;
+    out[3 * i + 2] = o2;
+  }
+}
+
+int launch_preprocess(hipStream_t s, const uint8_t* img, int n, int h, int w, int norm, float* out) {
+  if (norm < 0 || norm > 2) {
+    set_error("preprocess: unknown imgNorm %d", norm);
+    return FLM_ERR_ARG;
+  }
+  const size_t npix = (size_t)n * h * w;
+  const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+  preprocess_kernel<<<blocks > 0 ? blocks : 1, 256, 0, s>>>(img, out, npix, norm);
+  FLM_LAUNCH_CHECK("preprocess_kernel");
+  return FLM_OK;
+}
+
+// ---- least-squares similarity (no reflection) from K landmark pairs -----------------------------------
+// Complex form: dst ~ alpha*src + beta, alpha = sum(conj(p')q') / sum|p'|^2 over centred points.
+// Landmarks the decode rejected ((-1,-1), utils/metrics.py:78-79) are left out; fewer than two
+// usable points (or a degenerate cloud) gives the identity.  One thread per face, float64,
+// sequential sums in landmark order.
+__global__ void similarity_kernel(const double* __restrict__ lm, const double* __restrict__ tmpl, int n, int k,
+                                  float* __restrict__ m) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const double* p = lm + (size_t)f * k * 2;
+  double mpx = 0, mpy = 0, mqx = 0, mqy = 0;
+  int cnt = 0;
+  for (int i = 0; i < k; ++i) {
+    if (p[2 * i] < 0.0 || p[2 * i + 1] < 0.0) continue;
+    mpx += p[2 * i]; mpy += p[2 * i + 1];
+    mqx += tmpl[2 * i]; mqy += tmpl[2 * i + 1];
+    ++cnt;
+  }
+  double a = 1.0, b = 0.0, tx = 0.0, ty = 0.0;
+  if (cnt >= 2) {
+    mpx /= cnt; mpy /= cnt; mqx /= cnt; mqy /= cnt;
+    double sa = 0, sb = 0, var = 0;
+    for (int i = 0; i < k; ++i) {
+      if (p[2 * i] < 0.0 || p[2 * i + 1] < 0.0) continue;
+      const double px = p[2 * i] - mpx, py = p[2 * i + 1] - mpy;
+      const double qx = tmpl[2 * i] - mqx, qy = tmpl[2 * i + 1] - mqy;
+      sa += px * qx + py * qy;
+      sb += px * qy - py * qx;
+      var += px * px + py * py;
+    }
+    if (var > 0.0) {
+      a = sa / var;
+      b = sb / var;
+      tx = mqx - (a * mpx - b * mpy);
+      ty = mqy - (b * mpx + a * mpy);
+    }
+  }
+  float* o = m + (size_t)f * 6;
+  o[0] = (float)a; o[1] = (float)(-b); o[2] = (float)tx;
+  o[3] = (float)b; o[4] = (float)a;    o[5] = (float)ty;
+}
+
+int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, float* m) {
+  if (n <= 0 || k <= 0) {
+    set_error("similarity: bad sizes n=%d k=%d", n, k);
+    return FLM_ERR_SHAPE;
+  }
+  similarity_kernel<<<cdiv(n, 64), 64, 0, s>>>(lm, tmpl, n, k, m);
+  FLM_LAUNCH_CHECK("similarity_kernel");
+  return FLM_OK;
+}
+
+// ---- alignment warp: inverse-map bilinear, edge clamp, explicit fma order ------------------------------
+// M maps source pixel coords to aligned coords; each output pixel samples the source at M^-1 (xd, yd).
+// The arithmetic below is the specification (oracle/warp_ref.py restates it operation by operation):
+//   det  = fma(m00, m11, -(m01*m10));  idet = 1/det
+//   i00 = m11*idet; i01 = -m01*idet; i10 = -m10*idet; i11 = m00*idet
+//   i02 = -fma(i00, m02, i01*m12);     i12 = -fma(i10, m02, i11*m12)
+//   xs = fma(i00, xd, fma(i01, yd, i02));  ys = fma(i10, xd, fma(i11, yd, i12))
+//   clamp xs to [0, Ws-1], ys to [0, Hs-1]   (skimage warp mode="edge", data/generator.py:200)
+//   x0 = floor(xs), fx = xs-x0, x1 = min(x0+1, Ws-1)  (same for y)
+//   top = fma(fx, p01-p00, p00); bot = fma(fx, p11-p10, p10); out = fma(fy, bot-top, top)
+template <bool U8>
+__global__ __launch_bounds__(256) void warp_kernel(const void* __restrict__ src, int hs, int ws,
+                                                   const float* __restrict__ m, float* __restrict__ dst, int hd,
+                                                   int wd) {
+  const int f = blockIdx.y;
+  const float* mm = m + (size_t)f * 6;
+  const float m00 = mm[0], m01 = mm[1], m02 = mm[2], m10 = mm[3], m11 = mm[4], m12 = mm[5];
+  const float det = fmaf(m00, m11, -(m01 * m10));
+  const float idet = 1.0f / det;
+  const float i00 = m11 * idet, i01 = -m01 * idet, i10 = -m10 * idet, i11 = m00 * idet;
+  const float i02 = -fmaf(i00, m02, i01 * m12), i12 = -fmaf(i10, m02, i11 * m12);
+  const size_t sbase = (size_t)f * hs * ws * 3;
+  const int npix = hd * wd;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+    const float xd = (float)(p % wd), yd = (float)(p / wd);
+    float xs = fmaf(i00, xd, fmaf(i01, yd, i02));
+    float ys = fmaf(i10, xd, fmaf(i11, yd, i12));
+    xs = fminf(fmaxf(xs, 0.f), (float)(ws - 1));
+    ys = fminf(fmaxf(ys, 0.f), (float)(hs - 1));
+    const float xf = floorf(xs), yf = floorf(ys);
+    const float fx = xs - xf, fy = ys - yf;
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int x1 = min(x0 + 1, ws - 1), y1 = min(y0 + 1, hs - 1);
+    const size_t o00 = sbase + ((size_t)y0 * ws + x0) * 3, o01 = sbase + ((size_t)y0 * ws + x1) * 3;
+    const size_t o10 = sbase + ((size_t)y1 * ws + x0) * 3, o11 = sbase + ((size_t)y1 * ws + x1) * 3;
+    float* d = dst + ((size_t)f * npix + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float p00, p01, p10, p11;
+      if (U8) {
+        const uint8_t* s8 = reinterpret_cast<const uint8_t*>(src);
+        p00 = (float)s8[o00 + c]; p01 = (float)s8[o01 + c]; p10 = (float)s8[o10 + c]; p11 = (float)s8[o11 + c];
+      } else {
+        const float* sf = reinterpret_cast<const float*>(src);
+        p00 = sf[o00 + c]; p01 = sf[o01 + c]; p10 = sf[o10 + c]; p11 = sf[o11 + c];
+      }
+      const float top = fmaf(fx, p01 - p00, p00);
+      const float bot = fmaf(fx, p11 - p10, p10);
+      d[c] = fmaf(fy, bot - top, top);
+    }
+  }
+}
+
+int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, int ws, const float* m, float* dst,
+                int hd, int wd) {
+  if (n <= 0 || hs <= 0 || ws <= 0 || hd <= 0 || wd <= 0 || n > 65535) {
+    set_error("warp: bad sizes");
+    return FLM_ERR_SHAPE;
+  }
+  int bx = cdiv(hd * wd, 256);
+  if (bx > 1024) bx = 1024;
+  dim3 grid(bx, n);
+  if (src_is_u8) warp_kernel<true><<<grid, 256, 0, s>>>(src, hs, ws, m, dst, hd, wd);
+  else warp_kernel<false><<<grid, 256, 0, s>>>(src, hs, ws, m, dst, hd, wd);
+  FLM_LAUNCH_CHECK("warp_kernel");
+  return FLM_OK;
+}
+
+// ---- crop front-end: K boxes of one frame -> model-size uint8 BGR crops ------------------------------
+// Shape of detect_marks' crop + cv2.resize (reference prediction.py:80-82).  cv2's INTER_LINEAR uses
+// fixed-point weights that cannot be pinned here (cv2 absent): the resample is defined in fp32 instead:
+//   sx = (x + 0.5) * (bw / out_w) - 0.5 + x0   (pixel-centre convention), clamped to the FRAME
+//   bilinear as in the warp, result rounded to nearest-even and clamped to [0,255].
+__global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frame, int fh, int fw,
+                                                          const int32_t* __restrict__ boxes, uint8_t* __restrict__ out,
+                                                          int oh, int ow) {
+  const int k = blockIdx.y;
+  const int bx0 = boxes[4 * k + 0], by0 = boxes[4 * k + 1], bx1 = boxes[4 * k + 2], by1 = boxes[4 * k + 3];
+  const float sxs = (float)(bx1 - bx0) / (float)ow, sys = (float)(by1 - by0) / (float)oh;
+  const int npix = oh * ow;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+    const int x = p % ow, y = p / ow;
+    float xs = fmaf((float)x + 0.5f, sxs, -0.5f) + (float)bx0;
+    float ys = fmaf((float)y + 0.5f, sys, -0.5f) + (float)by0;
+    xs = fminf(fmaxf(xs, 0.f), (float)(fw - 1));
+    ys = fminf(fmaxf(ys, 0.f), (float)(fh - 1));
+    const float xf = floorf(xs), yf = floorf(ys);
+    const float fx = xs - xf, fy = ys - yf;
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int x1 = min(x0 + 1, fw - 1), y1 = min(y0 + 1, fh - 1);
+    const uint8_t* r0 = frame + ((size_t)y0 * fw) * 3;
+    const uint8_t* r1 = frame + ((size_t)y1 * fw) * 3;
+    uint8_t* d = out + ((size_t)k * npix + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c];
+      const float p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
+      const float top = fmaf(fx, p01 - p00, p00);
+      const float bot = fmaf(fx, p11 - p10, p10);
+      const float v = fmaf(fy, bot - top, top);
+      d[c] = (uint8_t)fminf(fmaxf(rintf(v), 0.f), 255.f);
+    }
+  }
+}
+
+int launch_crop_resize(hipStream_t s, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,
+                       uint8_t* out, int oh, int ow) {
+  if (k <= 0 || fh <= 0 || fw <= 0 || oh <= 0 || ow <= 0 || k > 65535) {
+    set_error("crop_resize: bad sizes");
+    return FLM_ERR_SHAPE;
+  }
+  int bx = cdiv(oh * ow, 256);
+  if (bx > 1024) bx = 1024;
+  crop_resize_kernel<<<dim3(bx, k), 256, 0, s>>>(frame, fh, fw, boxes, out, oh, ow);
+  FLM_LAUNCH_CHECK("crop_resize_kernel");
+  return FLM_OK;
+}
+
+}  // namespace flm

@@ -1,0 +1,193 @@
+// Weight repacking: Keras layouts -> the layouts the gfx950 kernels read.
+// Replaces keras `model.load_weights` (reference prediction.py:128) on the device side.
+#include "flm_common.h"
+
+namespace flm {
+
+ConvTGeom convt_geom(int C) {
+  ConvTGeom g;
+  g.C = C;
+  g.MT = cdiv(C, 16);
+  if (C == 68) {  // exact path for the 68-landmark model: K = 4*68 = 17 groups of 16
+    g.Cp = 68;
+    g.G = 17;
+  } else {  // generic path: channels padded to the class-tile size
+    g.Cp = 16 * g.MT;
+    g.G = 4 * g.MT;
+  }
+  return g;
+}
+
+static size_t take(size_t& cur, size_t bytes) {
+  size_t o = cur;
+  cur = align_up(cur + bytes, 256);
+  return o;
+}
+
+static ConvPack conv_pack(size_t& cur, int kh, int kw, int pad, int cin, int cout, int coutpad) {
+  ConvPack c;
+  c.kh = kh; c.kw = kw; c.pad = pad; c.cin = cin; c.cout = cout; c.coutpad = coutpad;
+  c.w = take(cur, sizeof(float) * (size_t)coutpad * kh * kw * cin);
+  c.scale = take(cur, sizeof(float) * coutpad);
+  c.shift = take(cur, sizeof(float) * coutpad);
+  return c;
+}
+
+Fcn8Pack fcn8_pack_layout(int C) {
+  Fcn8Pack L;
+  L.g = convt_geom(C);
+  size_t cur = 0;
+  L.enc1_w = take(cur, sizeof(float) * 64 * 32);
+  L.enc1_scale = take(cur, sizeof(float) * 64);
+  L.enc1_shift = take(cur, sizeof(float) * 64);
+  for (int i = 0; i < 4; ++i) L.enc[i] = conv_pack(cur, 3, 3, 1, kEncF[i], kEncF[i + 1], kEncF[i + 1]);
+  L.fc6 = conv_pack(cur, 7, 7, 3, kEncF[4], kFc, kFc);
+  L.fc7 = conv_pack(cur, 1, 1, 0, kFc, kFc, kFc);
+  // score convs write Cp channels (pad channels come out as exact zeros)
+  L.score5 = conv_pack(cur, 1, 1, 0, kFc, L.g.Cp, 128);
+  L.score4 = conv_pack(cur, 1, 1, 0, kEncF[3], L.g.Cp, 128);
+  L.score3 = conv_pack(cur, 1, 1, 0, kEncF[2], L.g.Cp, 128);
+  const size_t frag = sizeof(float) * (size_t)L.g.G * L.g.MT * 64 * 4;
+  L.up5 = take(cur, frag * 4);
+  L.up4 = take(cur, frag * 4);
+  L.up3 = take(cur, frag * 64);
+  L.total = cur;
+  return L;
+}
+
+// dst[o][(ky*kw+kx)*cin + c] = src[ky][kx][c][o]   (HWIO -> OHWI rows), zero rows for o >= cout
+__global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int kh, int kw, int cin,
+                                 int cout, int coutpad) {
+  const size_t K = (size_t)kh * kw * cin;
+  const size_t total = K * coutpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = i / K, k = i % K;
+    dst[i] = (o < (size_t)cout) ? src[k * cout + o] : 0.f;
+  }
+}
+
+// scale/shift of conv -> (BN) : y = conv*scale + shift
+//   with BN:  scale = gamma/sqrt(var+eps), shift = (bias-mean)*scale + beta
+//   without:  scale = 1, shift = bias
+__global__ void pack_affine_kernel(flm_conv_params p, float* __restrict__ scale, float* __restrict__ shift, int cout,
+                                   int coutpad) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= coutpad) return;
+  if (o >= cout) {
+    scale[o] = 0.f;
+    shift[o] = 0.f;
+    return;
+  }
+  const double b = p.bias ? (double)p.bias[o] : 0.0;
+  if (p.gamma) {
+    const double s = (double)p.gamma[o] / sqrt((double)p.var[o] + (double)kBnEps);
+    scale[o] = (float)s;
+    shift[o] = (float)((b - (double)p.mean[o]) * s + (double)p.beta[o]);
+  } else {
+    scale[o] = 1.f;
+    shift[o] = (float)b;
+  }
+}
+
+// enc1: dst[o][k], k = ky*9 + kx*3 + c, padded to 32
+__global__ void pack_enc1_kernel(const float* __restrict__ src /*[3][3][3][64]*/, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 32) return;
+  const int o = i >> 5, k = i & 31;
+  dst[i] = (k < 27) ? src[k * 64 + o] : 0.f;
+}
+
+// Transposed conv (kernel = 2s, stride s), Keras layout src[a][b][o][c] with a,b in [0,2s).
+// Output pixel (s*i0+a0, s*j0+b0) = sum_{di,dj in {0,1}} sum_c x[i0-di][j0-dj][c] * src[a0+s*di][b0+s*dj][o][c].
+// Fragment order: dst[phase=a0*s+b0][g][mt][lane][e], lane = (r = lane&15, q = lane>>4):
+//   class o = 16*mt + r, k = 16*g + 4*q + e, tap = k / Cp = 2*di+dj, c = k % Cp.
+__global__ void pack_convt_kernel(const float* __restrict__ src, float* __restrict__ dst, int s, ConvTGeom g) {
+  const size_t per_phase = (size_t)g.G * g.MT * 256;
+  const size_t total = per_phase * s * s;
+  const int ks = 2 * s;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int phase = (int)(i / per_phase);
+    size_t rem = i % per_phase;
+    const int e = rem & 3;
+    const int lane = (rem >> 2) & 63;
+    rem >>= 8;
+    const int mt = (int)(rem % g.MT);
+    const int gg = (int)(rem / g.MT);
+    const int r = lane & 15, q = lane >> 4;
+    const int o = 16 * mt + r;
+    const int k = 16 * gg + 4 * q + e;
+    const int tap = k / g.Cp, c = k % g.Cp;
+    float v = 0.f;
+    if (o < g.C && c < g.C && tap < 4) {
+      const int a0 = phase / s, b0 = phase % s;
+      const int a = a0 + s * (tap >> 1), b = b0 + s * (tap & 1);
+      v = src[(((size_t)a * ks + b) * g.C + o) * g.C + c];
+    }
+    dst[i] = v;
+  }
+}
+
+static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c, char* blob) {
+  if (!p.kernel || !p.bias) {
+    set_error("flm_fcn8_pack: conv layer lacks kernel or bias");
+    return FLM_ERR_ARG;
+  }
+  const size_t total = (size_t)c.coutpad * c.kh * c.kw * c.cin;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  pack_conv_kernel<<<blocks, 256, 0, s>>>(p.kernel, (float*)(blob + c.w), c.kh, c.kw, c.cin, c.cout, c.coutpad);
+  FLM_LAUNCH_CHECK("pack_conv_kernel");
+  // pad columns of the score convs (cout = Cp > C) must stay zero: affine kernel writes zeros for o >= cout_real
+  return FLM_OK;
+}
+
+int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8Pack& L, char* blob) {
+  // enc1
+  if (!p.enc[0].kernel || !p.enc[0].bias || !p.enc[0].gamma) {
+    set_error("flm_fcn8_pack: enc1 parameters missing");
+    return FLM_ERR_ARG;
+  }
+  pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(p.enc[0].kernel, (float*)(blob + L.enc1_w));
+  FLM_LAUNCH_CHECK("pack_enc1_kernel");
+  pack_affine_kernel<<<1, 64, 0, s>>>(p.enc[0], (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+  FLM_LAUNCH_CHECK("pack_affine_kernel");
+  for (int i = 0; i < 4; ++i) {
+    if (!p.enc[i + 1].gamma || !p.enc[i + 1].beta || !p.enc[i + 1].mean || !p.enc[i + 1].var) {
+      set_error("flm_fcn8_pack: encoder level %d lacks BatchNormalization tensors", i + 2);
+      return FLM_ERR_ARG;
+    }
+    int rc = pack_conv(s, p.enc[i + 1], L.enc[i], blob);
+    if (rc) return rc;
+    pack_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>(p.enc[i + 1], (float*)(blob + L.enc[i].scale),
+                                                                   (float*)(blob + L.enc[i].shift), L.enc[i].cout,
+                                                                   L.enc[i].coutpad);
+    FLM_LAUNCH_CHECK("pack_affine_kernel");
+  }
+  struct Item { const flm_conv_params* p; const ConvPack* c; int cout_real; };
+  const Item items[5] = {{&p.fc6, &L.fc6, kFc}, {&p.fc7, &L.fc7, kFc}, {&p.score5, &L.score5, C},
+                         {&p.score4, &L.score4, C}, {&p.score3, &L.score3, C}};
+  for (const Item& it : items) {
+    // Keras kernels of the score convs have C output columns; the packed rows C..coutpad-1 are zero.
+    ConvPack c = *it.c;
+    c.cout = it.cout_real;
+    int rc = pack_conv(s, *it.p, c, blob);
+    if (rc) return rc;
+    flm_conv_params q = *it.p;
+    q.gamma = q.beta = q.mean = q.var = nullptr;
+    pack_affine_kernel<<<cdiv(c.coutpad, 256), 256, 0, s>>>(q, (float*)(blob + c.scale), (float*)(blob + c.shift),
+                                                            it.cout_real, c.coutpad);
+    FLM_LAUNCH_CHECK("pack_affine_kernel");
+  }
+  if (!p.up5 || !p.up4 || !p.up3) {
+    set_error("flm_fcn8_pack: transposed-conv kernels missing");
+    return FLM_ERR_ARG;
+  }
+  pack_convt_kernel<<<256, 256, 0, s>>>(p.up5, (float*)(blob + L.up5), 2, L.g);
+  FLM_LAUNCH_CHECK("pack_convt_kernel");
+  pack_convt_kernel<<<256, 256, 0, s>>>(p.up4, (float*)(blob + L.up4), 2, L.g);
+  FLM_LAUNCH_CHECK("pack_convt_kernel");
+  pack_convt_kernel<<<2048, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 8, L.g);
+  FLM_LAUNCH_CHECK("pack_convt_kernel");
+  return FLM_OK;
+}
+
+}  // namespace flm

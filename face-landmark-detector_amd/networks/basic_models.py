@@ -1,0 +1,26 @@
+"""Registry mirror of keypoints_detector/networks/basic_models.py:59-64.
+
+`LANDMARKS_MODELS[name](n_classes, input_height=..., input_width=...)` is how the
+reference builds a model (prediction.py:122-126, training.py:129-133).  The reference's
+registry lists only ImageNet-backbone variants (whose constructors download weights) and a
+broken 'default'; it has no entry for the vanilla FCN-8 the hot path is built on, so this
+registry adds 'fcn_8' and points 'default' at it.
+"""
+from .fcn import fcn_8
+
+
+def _not_built(name, why):
+    def ctor(*a, **k):
+        raise NotImplementedError("%s is not built: %s" % (name, why))
+    return ctor
+
+
+_BACKBONE = "its encoder fetches ImageNet weights at construction (no network); SURVEY.md section 8 row F4"
+
+LANDMARKS_MODELS = {
+    "fcn_8": fcn_8,
+    "default": fcn_8,
+    "fcn_8_resnet50": _not_built("fcn_8_resnet50", _BACKBONE),
+    "fcn_8_mobilenet": _not_built("fcn_8_mobilenet", _BACKBONE),
+    "fcn_8_vgg": _not_built("fcn_8_vgg", _BACKBONE),
+}

@@ -1,0 +1,207 @@
+"""FCN-8 landmark model object backed by the HIP library.
+
+Host-side mirror of the Keras model that `fcn_8(n_classes, encoder=vanilla_encoder, ...)`
++ `get_segmentation_model` build (reference networks/fcn.py:10-51,89-126 and
+networks/utils.py:6-39): same constructor arguments, same attributes
+(`output_width, output_height, n_classes, input_height, input_width, model_name`,
+utils.py:32-37), `predict` with the Keras contract ([N,H,W,3] float32 in, [N,H'*W',C]
+float32 out, prediction.py:208) and `load_weights` (prediction.py:128).  All arithmetic is
+in libflm_hip.so; tensors live in HBM as torch tensors (allocation + streams only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .. import weights as W
+
+_OUT = {"probs": _lib.OUT_PROBS, "classmap": _lib.OUT_CLASSMAP, "landmarks": _lib.OUT_LANDMARKS,
+        "logits": _lib.OUT_LOGITS}
+
+
+def decode_mode_of(n_points: int):
+    """n_points < 1 -> all-pixel centroid (utils/metrics.py:58), else top-n (:66)."""
+    return (_lib.DECODE_ALL, 0) if n_points < 1 else (_lib.DECODE_TOPN, int(n_points))
+
+
+class Fcn8Model:
+    model_name = "fcn_8"
+
+    def __init__(self, n_classes, input_height=416, input_width=608, channels=3):
+        # defaults as networks/fcn.py:89-90
+        if channels != 3:
+            raise ValueError("only 3-channel input is built (reference default, fcn.py:90)")
+        if input_height % 32 or input_width % 32:
+            raise ValueError("input_height/input_width must be multiples of 32 (five 2x2 pools + "
+                             "the 8x8 / 16x16 crops of fcn.py:110,118), got %dx%d" % (input_height, input_width))
+        self.n_classes = int(n_classes)
+        self.input_height = int(input_height)
+        self.input_width = int(input_width)
+        # (H/8 - 1)*8 + 16 = H + 8: fcn.py:121-124 has no final crop
+        self.output_height = self.input_height + 8
+        self.output_width = self.input_width + 8
+        self._packed = None
+        self._ws = {}
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_weights(self, path_or_params):
+        """`model.load_weights(latest_weights)` (prediction.py:128).  Accepts the build's .npz
+        container (see weights.py) or a dict of Keras-layout arrays.  Returns None, which the
+        caller at prediction.py:130 accepts."""
+        params = W.load_weights_file(path_or_params) if isinstance(path_or_params, str) else path_or_params
+        self.set_weights(params)
+        return None
+
+    def set_weights(self, params: dict):
+        import torch
+        lib = _lib.load()
+        dev = _lib.require_gpu()
+        W.check_params(params, self.n_classes)
+        held = []
+
+        def up(name):
+            t = torch.from_numpy(np.ascontiguousarray(params[name], dtype=np.float32)).to(dev)
+            held.append(t)
+            return t.data_ptr()
+
+        def conv(name, bn):
+            cp = _lib.ConvParams()
+            cp.kernel = up(name + "/kernel")
+            cp.bias = up(name + "/bias")
+            if bn:
+                cp.gamma = up(name + "/gamma")
+                cp.beta = up(name + "/beta")
+                cp.mean = up(name + "/moving_mean")
+                cp.var = up(name + "/moving_variance")
+            return cp
+
+        p = _lib.Fcn8Params()
+        for i in range(5):
+            p.enc[i] = conv("enc%d" % (i + 1), True)
+        p.fc6 = conv("fc6", False)
+        p.fc7 = conv("fc7", False)
+        p.score5 = conv("score5", False)
+        p.score4 = conv("score4", False)
+        p.score3 = conv("score3", False)
+        p.up5 = up("up5/kernel")
+        p.up4 = up("up4/kernel")
+        p.up3 = up("up3/kernel")
+        nbytes = lib.flm_fcn8_packed_bytes(self.n_classes, _lib.FLM_F32)
+        if nbytes == 0:
+            raise _lib.FlmError("n_classes=%d is outside what the kernels cover" % self.n_classes)
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.flm_fcn8_pack(_lib.stream_ptr(), C.byref(p), self.n_classes, _lib.FLM_F32,
+                                     _lib.ptr(packed), nbytes), "flm_fcn8_pack")
+        torch.cuda.current_stream().synchronize()  # the Keras-layout copies die with `held`
+        self._packed = packed
+
+    # ---- forward ------------------------------------------------------------------------------
+    def _workspace(self, n, out_mode, dmode, npts):
+        import torch
+        key = (n, out_mode, dmode, npts)
+        ws = self._ws.get(key)
+        if ws is None:
+            lib = _lib.load()
+            nbytes = lib.flm_fcn8_workspace_bytes(n, self.input_height, self.input_width, self.n_classes,
+                                                  _lib.FLM_F32, out_mode, dmode, npts)
+            if nbytes == 0:
+                raise _lib.FlmError("workspace query failed: %s" % lib.flm_last_error().decode())
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=_lib.require_gpu())
+            self._ws[key] = ws
+        return ws
+
+    def forward_device(self, x, out="probs", n_points=0, thresh=0.0, out_tensor=None):
+        """One launch sequence on the current stream; everything stays in HBM.
+
+        x: torch CUDA tensor [N,H,W,3], uint8 (raw BGR crop: preprocess fused) or float32
+           (already preprocessed, what model.predict receives).
+        out: "probs" float32 [N,H'*W',C] | "classmap" int32 [N,H',W'] |
+             "landmarks" float64 [N,C,2] | "logits" float32 [N,H',W',C].
+        """
+        import torch
+        lib = _lib.load()
+        if self._packed is None:
+            raise _lib.FlmError("model has no weights: call load_weights()/set_weights() first")
+        if x.dim() != 4 or x.shape[1] != self.input_height or x.shape[2] != self.input_width or x.shape[3] != 3:
+            raise ValueError("expected [N,%d,%d,3], got %s" % (self.input_height, self.input_width, tuple(x.shape)))
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError("forward_device needs a contiguous CUDA tensor")
+        if x.dtype == torch.uint8:
+            fmt = _lib.IN_U8_BGR
+        elif x.dtype == torch.float32:
+            fmt = _lib.IN_F32_RGB
+        else:
+            raise ValueError("input dtype must be uint8 (BGR) or float32 (preprocessed)")
+        n = int(x.shape[0])
+        om = _OUT[out]
+        dmode, npts = decode_mode_of(n_points) if om == _lib.OUT_LANDMARKS else (0, 0)
+        oh, ow, c = self.output_height, self.output_width, self.n_classes
+        shape, dt = {
+            _lib.OUT_PROBS: ((n, oh * ow, c), torch.float32),
+            _lib.OUT_LOGITS: ((n, oh, ow, c), torch.float32),
+            _lib.OUT_CLASSMAP: ((n, oh, ow), torch.int32),
+            _lib.OUT_LANDMARKS: ((n, c, 2), torch.float64),
+        }[om]
+        if out_tensor is None:
+            out_tensor = torch.empty(shape, dtype=dt, device=x.device)
+        elif tuple(out_tensor.shape) != shape or out_tensor.dtype != dt or not out_tensor.is_contiguous():
+            raise ValueError("out_tensor must be contiguous %s %s" % (shape, dt))
+        ws = self._workspace(n, om, dmode, npts)
+        _lib.check(lib.flm_fcn8_forward(_lib.stream_ptr(), _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
+                                        self.input_height, self.input_width, c, _lib.FLM_F32, om, dmode, npts,
+                                        float(thresh), _lib.ptr(out_tensor), _lib.ptr(ws), ws.numel()),
+                   "flm_fcn8_forward")
+        return out_tensor
+
+    def intermediate(self, name, n, out="probs", n_points=0):
+        """View of a named workspace tensor of the last forward with the same (n, out) (tests)."""
+        import torch
+        lib = _lib.load()
+        om = _OUT[out]
+        dmode, npts = decode_mode_of(n_points) if om == _lib.OUT_LANDMARKS else (0, 0)
+        off = lib.flm_fcn8_workspace_offset(name.encode(), n, self.input_height, self.input_width, self.n_classes,
+                                            _lib.FLM_F32, om, dmode, npts)
+        if off < 0:
+            raise KeyError(name)
+        h, w = self.input_height, self.input_width
+        cp = 68 if self.n_classes == 68 else 16 * ((self.n_classes + 15) // 16)
+        shapes = {"f1": (h // 2, w // 2, 64), "f2": (h // 4, w // 4, 128), "f3": (h // 8, w // 8, 256),
+                  "f4": (h // 16, w // 16, 256), "f5": (h // 32, w // 32, 256),
+                  "fc6": (h // 32, w // 32, 4096), "fc7": (h // 32, w // 32, 4096),
+                  "score5": (h // 32, w // 32, cp), "fuse4": (h // 16, w // 16, cp),
+                  "seg_feats": (h // 8, w // 8, cp),
+                  "probs": (self.output_height * self.output_width, self.n_classes)}
+        shp = (n,) + shapes[name]
+        ws = self._workspace(n, om, dmode, npts)
+        cnt = int(np.prod(shp))
+        return ws[off:off + 4 * cnt].view(torch.float32).view(shp)
+
+    def predict(self, x, batch_size=32, verbose=0):
+        """Keras `Model.predict` contract (prediction.py:208): numpy in, numpy out, host round trip.
+        x: [N,H,W,3] float32 preprocessed (or uint8 BGR crops, then the preprocess is fused)."""
+        import torch
+        dev = _lib.require_gpu()
+        x = np.asarray(x)
+        if x.ndim != 4:
+            raise ValueError("predict expects [N,H,W,3]")
+        outs = []
+        for i in range(0, x.shape[0], batch_size):
+            xb = np.ascontiguousarray(x[i:i + batch_size])
+            if xb.dtype != np.uint8:
+                xb = xb.astype(np.float32, copy=False)
+            xd = torch.from_numpy(xb).to(dev)
+            outs.append(self.forward_device(xd, "probs").cpu().numpy())
+        return np.concatenate(outs, axis=0)
+
+
+def fcn_8(n_classes, encoder=None, input_height=416, input_width=608, channels=3):
+    """Signature of networks/fcn.py:89-90.  Only the vanilla conv/BN/ReLU encoder is built
+    (`encoder=None` or the string "vanilla"); the ImageNet backbones need a download the
+    reference performs at construction time (vgg16.py:76-79 etc.) and are out of scope."""
+    if encoder not in (None, "vanilla", "vanilla_encoder"):
+        raise NotImplementedError("only the vanilla encoder (networks/fcn.py:10-51) is built")
+    return Fcn8Model(n_classes, input_height=input_height, input_width=input_width, channels=channels)

@@ -75,6 +75,9 @@ def synth_fcn8_weights(n_classes: int = 68, seed: int = 2, channels: int = 3) ->
             if layer == "enc1":
                 # inputs are mean-subtracted bytes (|x| up to ~130): keep enc1 O(1)
                 w *= np.float32(1.0 / 64.0)
+            if layer.startswith("score"):
+                # keep the logits' spread O(1): an unsaturated softmax
+                w *= np.float32(0.125)
             p[name] = w
         elif tensor == "bias":
             p[name] = (rng.standard_normal(shp, dtype=np.float32) * np.float32(0.01))

@@ -1,0 +1,181 @@
+/*
+ * flm.h -- C ABI of the MI355X-native facial-landmark hot path (libflm_hip.so).
+ *
+ * The reference (sandyz1000/face-landmark-detector) is pure Python on
+ * TensorFlow/Keras: it has no FFI, plugin or operator registry.  The boundary it
+ * offers is a duck-typed model object plus a few functions; each entry point below
+ * names the reference interface it replaces (paths relative to the reference root).
+ * The Python host side (package `face-landmark-detector_amd`) binds these with
+ * ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer named *_dev is DEVICE memory
+ *    borrowed for the duration of the call; nothing is retained.
+ *  - every launch goes to the caller's stream (hipStream_t passed as void*);
+ *    no call synchronises the device or allocates memory.
+ *  - scratch memory is a caller-owned workspace sized by the matching
+ *    *_workspace_bytes query.
+ *  - return value: 0 = FLM_OK, negative = error; flm_last_error() returns a
+ *    thread-local message for the last failing call on this thread.
+ *  - layouts are NHWC ("channels_last", networks/config.py:5) throughout.
+ */
+#ifndef FLM_H_
+#define FLM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLM_ABI_VERSION 1
+
+typedef void* flm_stream_t; /* hipStream_t */
+
+enum flm_status {
+  FLM_OK = 0,
+  FLM_ERR_ARG = -1,         /* null pointer / bad enum */
+  FLM_ERR_SHAPE = -2,       /* shape outside what the kernels cover */
+  FLM_ERR_WORKSPACE = -3,   /* workspace too small */
+  FLM_ERR_HIP = -4,         /* a HIP runtime call failed */
+  FLM_ERR_UNSUPPORTED = -5  /* valid request this build does not implement */
+};
+
+enum flm_dtype { FLM_F32 = 0, FLM_BF16 = 1 };
+
+/* Input formats of the forward. */
+enum flm_input_format {
+  FLM_IN_U8_BGR = 0,  /* raw cv2 crop, uint8 [N,H,W,3] BGR: the sub_mean preprocess of
+                         get_image_array (data/generator.py:52-61) is fused into the
+                         first conv's loader */
+  FLM_IN_F32_RGB = 1  /* already preprocessed float32 [N,H,W,3], what model.predict
+                         receives at prediction.py:208 */
+};
+
+/* What flm_fcn8_forward writes to `out_dev`. */
+enum flm_output_mode {
+  FLM_OUT_PROBS = 0,     /* float32 [N, H'*W', C]: model.predict (networks/utils.py:28-30) */
+  FLM_OUT_CLASSMAP = 1,  /* int32 [N, H', W']: pr.argmax(axis=2) (prediction.py:209) */
+  FLM_OUT_LANDMARKS = 2, /* float64 [N, C, 2] (x,y): transfer_target (utils/metrics.py:102-109) */
+  FLM_OUT_LOGITS = 3     /* float32 [N, H', W', C] before the softmax (debug / tests) */
+};
+
+enum flm_decode_mode {
+  FLM_DECODE_ALL = 0, /* n_points < 1: full-map weighted centroid (utils/metrics.py:58-64) */
+  FLM_DECODE_TOPN = 1 /* weighted centroid of the n largest pixels (utils/metrics.py:66-77) */
+};
+
+enum flm_image_norm { /* imgNorm of get_image_array (data/generator.py:50-65) */
+  FLM_NORM_SUB_MEAN = 0,
+  FLM_NORM_SUB_AND_DIVIDE = 1,
+  FLM_NORM_DIVIDE = 2
+};
+
+int flm_abi_version(void);
+const char* flm_last_error(void);
+
+/* ---- weights -------------------------------------------------------------------
+ * Replaces keras `model.load_weights` (prediction.py:128).  Parameters arrive as
+ * device tensors in the KERAS layouts and are repacked on the device into one blob
+ * in the layouts the kernels read (OHWI rows for the implicit GEMMs, MFMA fragment
+ * order for the transposed convs, BatchNorm folded to scale/shift with eps = 1e-3).
+ */
+typedef struct flm_conv_params {
+  const float* kernel; /* Conv2D: HWIO (kh,kw,in,out) */
+  const float* bias;   /* [out] */
+  const float* gamma;  /* BatchNormalization, NULL for layers without BN */
+  const float* beta;
+  const float* mean;   /* moving_mean */
+  const float* var;    /* moving_variance */
+} flm_conv_params;
+
+typedef struct flm_fcn8_params {
+  flm_conv_params enc[5];  /* vanilla_encoder, networks/fcn.py:10-51: 3x3, F=64,128,256,256,256 */
+  flm_conv_params fc6;     /* fcn.py:98  7x7x256x4096 */
+  flm_conv_params fc7;     /* fcn.py:100 1x1x4096x4096 */
+  flm_conv_params score5;  /* fcn.py:103 1x1x4096xC */
+  flm_conv_params score4;  /* fcn.py:108 1x1x256xC on f4 */
+  flm_conv_params score3;  /* fcn.py:117 1x1x256xC on f3 */
+  const float* up5;        /* fcn.py:104 Conv2DTranspose (4,4,C,C) = (kh,kw,out,in), stride 2 */
+  const float* up4;        /* fcn.py:114 (4,4,C,C), stride 2 */
+  const float* up3;        /* fcn.py:121 (16,16,C,C), stride 8 */
+} flm_fcn8_params;
+
+size_t flm_fcn8_packed_bytes(int n_classes, int dtype);
+int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* params_dev_ptrs, int n_classes,
+                  int dtype, void* packed_dev, size_t packed_bytes);
+
+/* ---- forward -------------------------------------------------------------------
+ * Replaces `model.predict(x)` of the model built by fcn_8 + vanilla_encoder +
+ * get_segmentation_model (networks/fcn.py:89-126, networks/utils.py:6-39;
+ * call site prediction.py:208), optionally continued through the argmax of
+ * prediction.py:209 or the decode of utils/metrics.py:102-109.
+ * H and W must be multiples of 32; the output grid is H' = H+8, W' = W+8.
+ */
+size_t flm_fcn8_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode,
+                                int decode_mode, int n_points);
+int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format,
+                     int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                     int n_points, float thresh, void* out_dev, void* workspace_dev,
+                     size_t workspace_bytes);
+/* Byte offset inside the workspace of a named intermediate ("f1".."f5","fc6","fc7",
+ * "score5","fuse4","seg_feats","probs"), or -1: lets tests compare layer by layer. */
+int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype,
+                                  int out_mode, int decode_mode, int n_points);
+
+/* One named Conv2D layer of the model in isolation ("enc2".."enc5" with BN+ReLU+pool fused,
+ * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  Used by
+ * the layer parity tests and by bench.py to time the dominant kernel on its own stream. */
+int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const float* x_dev,
+                       float* y_dev, int n, int h, int w, int n_classes, int dtype);
+
+/* ---- measurement hook (bench.py) --------------------------------------------------
+ * When enabled, flm_fcn8_forward brackets each of its kernel launches with a hipEvent pair on
+ * the caller's stream (no synchronisation).  flm_profile_read(i, ...) waits for record i and
+ * returns its layer name and duration in ms; it returns 1 past the last record.
+ * Process-global, not thread-safe: a measurement aid, off by default. */
+int flm_profile_enable(int max_records);
+int flm_profile_reset(void);
+int flm_profile_read(int index, char* name_out, int name_cap, float* ms_out);
+int flm_profile_disable(void);
+
+/* ---- preprocess ----------------------------------------------------------------
+ * get_image_array (data/generator.py:29-69) for crops already at model size:
+ * uint8 BGR [N,H,W,3] -> float32 [N,H,W,3] (RGB for sub_mean). */
+int flm_preprocess(flm_stream_t stream, const uint8_t* img_bgr_dev, int n, int h, int w, int norm,
+                   float* out_dev);
+
+/* ---- decode --------------------------------------------------------------------
+ * transfer_target / transfer_xy_coord / get_average_xy (utils/metrics.py:46-109):
+ * float32 heatmaps [N,H,W,L] -> float64 [N,L,2] (x,y) in heatmap pixel units,
+ * (-1,-1) where mean(selected) <= thresh.  Ties at the n-th place: pixels are ordered
+ * by (value, flat index), the n largest are kept. */
+size_t flm_decode_workspace_bytes(int n, int h, int w, int l, int mode, int n_points);
+int flm_decode(flm_stream_t stream, const float* hm_dev, int n, int h, int w, int l, int mode,
+               int n_points, float thresh, double* out_dev, void* workspace_dev,
+               size_t workspace_bytes);
+
+/* ---- alignment (no reference implementation: README.md:1 states the intent only) --
+ * Least-squares similarity (Umeyama, 4 dof) mapping each face's K landmarks onto a
+ * template, returned as the 2x3 matrix M that maps SOURCE pixel coords to ALIGNED
+ * coords; and the inverse-map bilinear warp with edge clamp (the skimage
+ * `warp(..., mode="edge")` shape of data/generator.py:192-200). */
+int flm_similarity_from_landmarks(flm_stream_t stream, const double* lm_dev /*[N,K,2]*/,
+                                  const double* tmpl_dev /*[K,2]*/, int n, int k,
+                                  float* m_dev /*[N,2,3]*/);
+int flm_warp_affine(flm_stream_t stream, const void* src_dev /*[N,Hs,Ws,3]*/, int src_is_u8, int n,
+                    int hs, int ws, const float* m_dev /*[N,2,3] src->dst*/,
+                    float* dst_dev /*[N,Hd,Wd,3]*/, int hd, int wd);
+
+/* ---- crop front-end (detect_marks pre-processing, prediction.py:76-83) -----------
+ * Bilinear crop+resize of K boxes from one uint8 BGR frame into the model's input
+ * batch (uint8 BGR [K,out_h,out_w,3]); boxes are (x0,y0,x1,y1) int32, already squared by
+ * the host-side box maths. */
+int flm_crop_resize(flm_stream_t stream, const uint8_t* frame_dev, int fh, int fw,
+                    const int32_t* boxes_dev /*[K,4]*/, int k, uint8_t* out_dev, int out_h, int out_w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLM_H_ */

@@ -1,0 +1,139 @@
+"""CPU restatement of the alignment path (similarity estimate + bilinear warp) and of the crop
+front-end.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED against the reference: it contains no alignment code (README.md:1 states the
+intent only).  The spec is build-defined and written operation by
+operation in the kernel comments of csrc/flm_misc.hip; this file restates it in numpy.
+`tests/test_oracle_warp.py` cross-checks the geometry against scikit-image 0.18.3
+(`SimilarityTransform.estimate` + `warp(order=1, mode="edge")`, the call shape of the
+reference's only affine warp, data/generator.py:192-200) through fixtures generated with the
+second interpreter in the build container.
+
+fp32 fused multiply-add is emulated as float32(float64(a)*float64(b) + float64(c)); the product
+is exact in float64, so the only difference from a hardware fma is a possible double rounding
+(<= 1 ULP, the tolerance the GPU parity test uses).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+
+
+def fma(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def similarity_ref(lm: np.ndarray, tmpl: np.ndarray) -> np.ndarray:
+    """Least-squares similarity (rotation+uniform scale+translation, no reflection) mapping
+    landmarks [N,K,2] onto template [K,2]; float64 sequential sums; returns float32 [N,2,3].
+    Landmarks with a negative coordinate (decode rejects, utils/metrics.py:78-79) are left out."""
+    n, k, _ = lm.shape
+    out = np.zeros((n, 2, 3), np.float32)
+    for f in range(n):
+        p = lm[f].astype(np.float64)
+        ok = [i for i in range(k) if not (p[i, 0] < 0.0 or p[i, 1] < 0.0)]
+        a, b, tx, ty = 1.0, 0.0, 0.0, 0.0
+        if len(ok) >= 2:
+            mpx = mpy = mqx = mqy = 0.0
+            for i in ok:
+                mpx += p[i, 0]; mpy += p[i, 1]; mqx += float(tmpl[i, 0]); mqy += float(tmpl[i, 1])
+            cnt = len(ok)
+            mpx /= cnt; mpy /= cnt; mqx /= cnt; mqy /= cnt
+            sa = sb = var = 0.0
+            for i in ok:
+                px, py = p[i, 0] - mpx, p[i, 1] - mpy
+                qx, qy = float(tmpl[i, 0]) - mqx, float(tmpl[i, 1]) - mqy
+                sa += px * qx + py * qy
+                sb += px * qy - py * qx
+                var += px * px + py * py
+            if var > 0.0:
+                a, b = sa / var, sb / var
+                tx = mqx - (a * mpx - b * mpy)
+                ty = mqy - (b * mpx + a * mpy)
+        out[f] = [[a, -b, tx], [b, a, ty]]
+    return out
+
+
+def _bilinear(src_f32, xs, ys):
+    hs, ws = src_f32.shape[:2]
+    xs = np.minimum(np.maximum(xs, f32(0)), f32(ws - 1))
+    ys = np.minimum(np.maximum(ys, f32(0)), f32(hs - 1))
+    xf, yf = np.floor(xs), np.floor(ys)
+    fx, fy = (xs - xf).astype(np.float32), (ys - yf).astype(np.float32)
+    x0, y0 = xf.astype(np.int64), yf.astype(np.int64)
+    x1, y1 = np.minimum(x0 + 1, ws - 1), np.minimum(y0 + 1, hs - 1)
+    p00, p01 = src_f32[y0, x0], src_f32[y0, x1]
+    p10, p11 = src_f32[y1, x0], src_f32[y1, x1]
+    top = fma(fx[..., None], p01 - p00, p00)
+    bot = fma(fx[..., None], p11 - p10, p10)
+    return fma(fy[..., None], bot - top, top)
+
+
+def warp_affine_ref(src: np.ndarray, m: np.ndarray, hd: int, wd: int) -> np.ndarray:
+    """src [N,Hs,Ws,3] uint8 or float32, m float32 [N,2,3] (source -> aligned coords);
+    returns float32 [N,hd,wd,3].  Inverse map + bilinear + edge clamp (csrc/flm_misc.hip)."""
+    n = src.shape[0]
+    out = np.zeros((n, hd, wd, 3), np.float32)
+    yd, xd = np.mgrid[0:hd, 0:wd]
+    xd, yd = xd.astype(np.float32), yd.astype(np.float32)
+    for f in range(n):
+        m00, m01, m02, m10, m11, m12 = [f32(v) for v in m[f].reshape(-1)]
+        det = fma(m00, m11, -(m01 * m10))
+        idet = f32(1.0) / det
+        i00, i01, i10, i11 = m11 * idet, -m01 * idet, -m10 * idet, m00 * idet
+        i02 = -fma(i00, m02, i01 * m12)
+        i12 = -fma(i10, m02, i11 * m12)
+        xs = fma(i00, xd, fma(i01, yd, i02))
+        ys = fma(i10, xd, fma(i11, yd, i12))
+        out[f] = _bilinear(src[f].astype(np.float32), xs, ys)
+    return out
+
+
+def crop_resize_ref(frame: np.ndarray, boxes: np.ndarray, oh: int, ow: int) -> np.ndarray:
+    """frame [H,W,3] uint8, boxes int [K,4] (x0,y0,x1,y1) -> uint8 [K,oh,ow,3] (csrc/flm_misc.hip)."""
+    k = boxes.shape[0]
+    out = np.zeros((k, oh, ow, 3), np.uint8)
+    y, x = np.mgrid[0:oh, 0:ow]
+    for i in range(k):
+        bx0, by0, bx1, by1 = [int(v) for v in boxes[i]]
+        sxs = f32(bx1 - bx0) / f32(ow)
+        sys_ = f32(by1 - by0) / f32(oh)
+        xs = (fma(x.astype(np.float32) + f32(0.5), sxs, f32(-0.5)) + f32(bx0)).astype(np.float32)
+        ys = (fma(y.astype(np.float32) + f32(0.5), sys_, f32(-0.5)) + f32(by0)).astype(np.float32)
+        v = _bilinear(frame.astype(np.float32), xs, ys)
+        out[i] = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    return out
+
+
+# ---- detect_marks box maths (reference prediction.py:36-94), integer exact -------------------------
+def square_box_ref(face):
+    """offset_y = int(abs((y1-y0)*0.1)); move down; square by symmetric integer expansion."""
+    offset_y = int(abs((face[3] - face[1]) * 0.1))                      # :76
+    left_x, top_y, right_x, bottom_y = face[0], face[1] + offset_y, face[2], face[3] + offset_y  # :67-74,77
+    box_width, box_height = right_x - left_x, bottom_y - top_y          # :40-41
+    diff = box_height - box_width                                       # :44
+    delta = int(abs(diff) / 2)                                          # :45
+    if diff == 0:
+        return [left_x, top_y, right_x, bottom_y]
+    elif diff > 0:                                                      # :50-54
+        left_x -= delta
+        right_x += delta
+        if diff % 2 == 1:
+            right_x += 1
+    else:                                                               # :56-60
+        top_y -= delta
+        bottom_y += delta
+        if diff % 2 == 1:
+            bottom_y += 1
+    assert (right_x - left_x) == (bottom_y - top_y)
+    return [left_x, top_y, right_x, bottom_y]
+
+
+def backproject_marks_ref(marks01: np.ndarray, facebox) -> np.ndarray:
+    """prediction.py:91-94: marks in [0,1] -> image coords, truncated to unsigned ints."""
+    marks = np.array(marks01, dtype=np.float32).reshape(-1, 2).copy()
+    marks *= (facebox[2] - facebox[0])
+    marks[:, 0] += facebox[0]
+    marks[:, 1] += facebox[1]
+    return marks.astype(np.uint)

@@ -1,0 +1,152 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/flm.h declares
+(no compute calls without a GPU), and the host logic that mirrors the reference interface."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import flm_amd  # noqa: F401
+from flm_amd import _lib, alignment, distributed, prediction
+from flm_amd.networks import LANDMARKS_MODELS, Fcn8Model
+from flm_amd import weights as W
+from oracle import warp_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "flm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(flm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 16
+    for s in syms:
+        assert hasattr(lib, s), "libflm_hip.so lacks %s" % s
+    assert set(_lib.EXPORTS) == set(syms), set(_lib.EXPORTS) ^ set(syms)
+    assert _lib.load().flm_abi_version() == _lib.ABI_VERSION
+
+
+def test_size_queries_answer_without_a_gpu():
+    lib = _lib.load()
+    nbytes = lib.flm_fcn8_packed_bytes(68, _lib.FLM_F32)
+    # 71,361,868 conv parameters: the blob is that plus padding rows
+    assert 4 * 71_361_868 < nbytes < 4 * 71_361_868 * 1.02
+    assert lib.flm_fcn8_packed_bytes(68, _lib.FLM_BF16) == 0          # not built: says so
+    assert lib.flm_fcn8_packed_bytes(1000, _lib.FLM_F32) == 0
+    ws = lib.flm_fcn8_workspace_bytes(64, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN, 4)
+    assert ws > 64 * 264 * 264 * 68 * 4
+    assert lib.flm_fcn8_workspace_bytes(1, 250, 256, 68, _lib.FLM_F32, 0, 0, 0) == 0   # H not multiple of 32
+    assert b"multiples of 32" in lib.flm_last_error()
+    assert lib.flm_decode_workspace_bytes(2, 264, 264, 68, _lib.DECODE_TOPN, 4) > 0
+
+
+def test_null_arguments_are_rejected_not_dereferenced():
+    lib = _lib.load()
+    assert lib.flm_decode(None, None, 1, 8, 8, 1, 0, 0, 0.0, None, None, 0) == -1
+    assert lib.flm_fcn8_forward(None, None, None, 0, 1, 32, 32, 68, 0, 0, 0, 0, 0.0, None, None, 0) == -1
+    assert lib.flm_warp_affine(None, None, 1, 1, 8, 8, None, None, 8, 8) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    m = LANDMARKS_MODELS["fcn_8"](68, input_height=32, input_width=32)
+    with pytest.raises(_lib.FlmError):
+        m.predict(np.zeros((1, 32, 32, 3), np.float32))
+    with pytest.raises(_lib.FlmError):
+        m.load_weights({k: np.zeros(s, np.float32) for k, s in W.fcn8_param_shapes(68).items()})
+    from flm_amd.utils import metrics
+    with pytest.raises(_lib.FlmError):
+        metrics.transfer_target(np.zeros((1, 8, 8, 2), np.float32))
+
+
+def test_model_object_contract():
+    # attributes of networks/utils.py:32-37; defaults of networks/fcn.py:89-90
+    m = LANDMARKS_MODELS["fcn_8"](68)
+    assert (m.input_height, m.input_width) == (416, 608)
+    assert (m.output_height, m.output_width, m.n_classes, m.model_name) == (424, 616, 68, "fcn_8")
+    m = LANDMARKS_MODELS["default"](68, input_height=256, input_width=256)
+    assert isinstance(m, Fcn8Model) and (m.output_height, m.output_width) == (264, 264)
+    with pytest.raises(ValueError):
+        LANDMARKS_MODELS["fcn_8"](68, input_height=250, input_width=256)
+    for name in ("fcn_8_resnet50", "fcn_8_mobilenet", "fcn_8_vgg"):   # registry keys of basic_models.py:59-64
+        with pytest.raises(NotImplementedError):
+            LANDMARKS_MODELS[name](68, input_height=224, input_width=224)
+
+
+def test_weight_container_roundtrip(tmp_path):
+    shapes = W.fcn8_param_shapes(5)
+    assert shapes["fc6/kernel"] == (7, 7, 256, 4096) and shapes["up3/kernel"] == (16, 16, 5, 5)
+    assert sum(int(np.prod(s)) for k, s in W.fcn8_param_shapes(68).items()
+               if k.endswith("kernel") or k.endswith("bias")) == 71_361_868
+    small = {k: np.full(s, 0.5, np.float32) for k, s in shapes.items() if "fc" not in k}
+    with pytest.raises(KeyError):
+        W.check_params(small, 5)
+    p = W.synth_fcn8_weights(5, seed=3)
+    W.check_params(p, 5)
+    q = W.synth_fcn8_weights(5, seed=3)
+    assert all(np.array_equal(p[k], q[k]) for k in p)
+    bad = dict(p)
+    bad["up4/kernel"] = np.zeros((4, 4, 5, 6), np.float32)
+    with pytest.raises(ValueError):
+        W.check_params(bad, 5)
+
+
+def test_keypts_predict_error_behaviour():
+    # prediction.py:166-174
+    with pytest.raises(ValueError, match="Both model and checkpoint_path cannot be empty"):
+        prediction.keypts_predict()
+    m = LANDMARKS_MODELS["fcn_8"](68, input_height=32, input_width=32)
+    with pytest.raises(AssertionError):
+        prediction.keypts_predict(model=m, inp=None)
+    with pytest.raises(AssertionError):
+        prediction.keypts_predict(model=m, inp=123)
+    with pytest.raises(AssertionError, match="Checkpoint not found"):
+        prediction.model_from_checkpoint_path("/nonexistent/ckpt")
+
+
+def test_find_latest_checkpoint(tmp_path):
+    base = str(tmp_path / "ck")
+    assert prediction.find_latest_checkpoint(base) is None
+    with pytest.raises(ValueError):
+        prediction.find_latest_checkpoint(base, fail_safe=False)
+    for e in (1, 12, 3):
+        open("%s.%05d.npz" % (base, e), "w").close()
+    open(base + "_config.json", "w").write(json.dumps({"model_class": "fcn_8", "n_classes": 68}))
+    assert prediction.find_latest_checkpoint(base).endswith("ck.00012.npz")
+
+
+def test_box_maths_matches_oracle():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        x0, y0 = int(rng.integers(-20, 1800)), int(rng.integers(-20, 1000))
+        face = [x0, y0, x0 + int(rng.integers(1, 400)), y0 + int(rng.integers(1, 400))]
+        assert prediction.face_boxes([face])[0] == warp_ref.square_box_ref(face)
+
+
+def test_shard_range_partitions():
+    for total in (0, 1, 7, 64, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        distributed.shard_range(4, 4, 4)
+
+
+def test_canonical_template():
+    t = alignment.canonical_template(68, 256, 256)
+    assert t.shape == (68, 2) and t.min() >= 0 and t.max() <= 255
+    assert len({tuple(np.round(p, 6)) for p in t}) == 68
+    assert np.array_equal(t, alignment.canonical_template(68, 256, 256))
+    assert alignment.canonical_template(5, 112, 112).shape == (5, 2)
