@@ -95,6 +95,11 @@ def load():
         raise FlmError(
             "libflm_hip.so is not built (%s). Build it with `python face-landmark-detector_amd/build.py`; "
             "this package has no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Import torch FIRST so the
+    # dynamic linker binds this library to that same runtime (same SONAME) -- loading ours first would
+    # pull /opt/rocm's copy in beside torch's: two HIP runtimes in one process, and launches on torch's
+    # streams / pointers fail with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):

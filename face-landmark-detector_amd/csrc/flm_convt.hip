@@ -76,28 +76,38 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
   const size_t phase_f4 = (size_t)G * MT * 64;
   const float4* wbase = reinterpret_cast<const float4*>(a.wf) + (size_t)a0 * s * phase_f4;
   const int total = s * NCH;
-  float4 st[NLD];
-  auto issue = [&](int seq) {
-    const int b0 = seq / NCH, ch = seq % NCH;
-    const int ng = (G - ch * GCH) < GCH ? (G - ch * GCH) : GCH;
-    const int cnt = ng * MT * 64;
-    const float4* src = wbase + (size_t)b0 * phase_f4 + (size_t)ch * CHUNK_F4;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      st[i] = src[idx < cnt ? idx : 0];
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < CHUNK_F4) lds[buf * CHUNK_F4 + idx] = st[i];
-    }
-  };
+  // Staging registers are NAMED scalars: an indexed array here (even fully unrolled) is left in scratch
+  // memory by hipcc when it is written and read under separate `if (more)` branches.
+  static_assert(NLD <= 9, "staging covers at most 9 x 16 bytes per thread");
+  float4 st0, st1, st2, st3, st4, st5, st6, st7, st8;
+#define FLM_FOR_ST(X) X(0, st0) X(1, st1) X(2, st2) X(3, st3) X(4, st4) X(5, st5) X(6, st6) X(7, st7) X(8, st8)
+#define FLM_LD1(I, R)                                \
+  if constexpr (I < NLD) {                           \
+    const int idx = tid + 256 * I;                   \
+    R = src_[idx < cnt_ ? idx : 0];                  \
+  }
+#define FLM_ST1(I, R)                                \
+  if constexpr (I < NLD) {                           \
+    const int idx = tid + 256 * I;                   \
+    if (idx < CHUNK_F4) lds[bf_ * CHUNK_F4 + idx] = R; \
+  }
+#define FLM_ISSUE(SEQ)                                                                  \
+  {                                                                                     \
+    const int sq_ = (SEQ);                                                              \
+    const int b0_ = sq_ / NCH, ch_ = sq_ % NCH;                                         \
+    const int ng_ = (G - ch_ * GCH) < GCH ? (G - ch_ * GCH) : GCH;                      \
+    const int cnt_ = ng_ * MT * 64;                                                     \
+    const float4* src_ = wbase + (size_t)b0_ * phase_f4 + (size_t)ch_ * CHUNK_F4;      \
+    FLM_FOR_ST(FLM_LD1)                                                                 \
+  }
+#define FLM_STASH(BUF)                                                                  \
+  {                                                                                     \
+    const int bf_ = (BUF);                                                              \
+    FLM_FOR_ST(FLM_ST1)                                                                 \
+  }
 
-  issue(0);
-  stash(0);
+  FLM_ISSUE(0)
+  FLM_STASH(0)
   __syncthreads();
 
   int seq = 0;
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const bool more = seq + 1 < total;
-      if (more) issue(seq + 1);
+      if (more) FLM_ISSUE(seq + 1)
       const float4* wl = lds + (seq & 1) * CHUNK_F4;
 #pragma unroll
       for (int gl = 0; gl < GCH; ++gl) {
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
           for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[g].w, acc[m], 0, 0, 0);
         }
       }
-      if (more) stash((seq + 1) & 1);
+      if (more) FLM_STASH((seq + 1) & 1)
       __syncthreads();
       ++seq;
     }
@@ -225,6 +235,12 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
     }
   }
 }
+
+#undef FLM_ISSUE
+#undef FLM_STASH
+#undef FLM_FOR_ST
+#undef FLM_LD1
+#undef FLM_ST1
 
 template <int MT, int G>
 static int launch_t(hipStream_t st, const ConvTArgs& a) {

@@ -106,50 +106,66 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
     if (lane == 0) s_mask[wave] = mymask;
     __syncthreads();
     tapmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
-    tapmask = __builtin_amdgcn_readfirstlane((unsigned)tapmask) |
-              ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(tapmask >> 32)) << 32);
+    // readfirstlane returns a signed int: go through unsigned or bit 31 smears over bits 32..63
+    const unsigned tm_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tapmask);
+    const unsigned tm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tapmask >> 32));
+    tapmask = ((unsigned long long)tm_hi << 32) | (unsigned long long)tm_lo;
   }
   const int nit = __builtin_popcountll(tapmask) * a.cpt;
 
-  float4 ra[4], rb[4];
-  bool ok[4];
+  // per-row element offset of the centre pixel; per-tap displacement is wave-uniform
+  unsigned rowoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(((pn[j] * a.h + py[j]) * a.w + px[j]) * a.cin) + 4 * c8;
+  const float* wrow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wrow[j] = a.wt + (size_t)(n0 + r0 + 32 * j) * a.K + 4 * c8;
+
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
 
   // iterator over (valid tap, channel chunk)
   unsigned long long rem = tapmask;
   int cur_tap = __builtin_ctzll(rem);
   int cur_chunk = 0;
 
-  auto issue_loads = [&]() {
-    const int ky = cur_tap / a.kw - a.pad, kx = cur_tap % a.kw - a.pad;
-    const int koff = cur_tap * a.cin + cur_chunk * BK + 4 * c8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int iy = py[j] + ky, ix = px[j] + kx;
-      ok[j] = pv[j] && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-      // out-of-bounds rows load a valid address (pixel 0 of the tensor) and are zeroed at the LDS write,
-      // so the loads issue back to back with no branch around them
-      const size_t pix = ok[j] ? ((size_t)(pn[j] * a.h + iy) * a.w + ix) : 0;
-      ra[j] = *reinterpret_cast<const float4*>(a.x + pix * a.cin + cur_chunk * BK + 4 * c8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      rb[j] = *reinterpret_cast<const float4*>(a.wt + (size_t)(n0 + r0 + 32 * j) * a.K + koff);
-    // advance
-    if (++cur_chunk == a.cpt) {
-      cur_chunk = 0;
-      rem &= rem - 1;
-      cur_tap = rem ? __builtin_ctzll(rem) : 0;
-    }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = r0 + 32 * j;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(As + buf * TILE_F + swz(row, c8)) = ok[j] ? ra[j] : z;
-      *reinterpret_cast<float4*>(Bs + buf * TILE_F + swz(row, c8)) = rb[j];
-    }
-  };
+  // Out-of-bounds rows load a valid address (their own centre pixel) and are zeroed at the LDS write,
+  // so the eight loads issue back to back with no branch around them.
+#define FLM_LOAD_A(J, RA, OK)                                                                        \
+  {                                                                                                  \
+    const int iy = py[J] + ky, ix = px[J] + kx;                                                      \
+    OK = pv[J] && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;                     \
+    const unsigned off = rowoff[J] + (OK ? (unsigned)tapdelta : 0u) + (unsigned)(cur_chunk * BK);  \
+    RA = *reinterpret_cast<const float4*>(a.x + off);                                                \
+  }
+#define FLM_ISSUE_LOADS()                                                             \
+  {                                                                                   \
+    const int ky = cur_tap / a.kw - a.pad, kx = cur_tap % a.kw - a.pad;               \
+    const int tapdelta = (ky * a.w + kx) * a.cin;                                     \
+    const int koff = cur_tap * a.cin + cur_chunk * BK;                                \
+    FLM_LOAD_A(0, ra0, ok0) FLM_LOAD_A(1, ra1, ok1) FLM_LOAD_A(2, ra2, ok2) FLM_LOAD_A(3, ra3, ok3) \
+    rb0 = *reinterpret_cast<const float4*>(wrow[0] + koff);                           \
+    rb1 = *reinterpret_cast<const float4*>(wrow[1] + koff);                           \
+    rb2 = *reinterpret_cast<const float4*>(wrow[2] + koff);                           \
+    rb3 = *reinterpret_cast<const float4*>(wrow[3] + koff);                           \
+    if (++cur_chunk == a.cpt) {                                                       \
+      cur_chunk = 0;                                                                  \
+      rem &= rem - 1;                                                                 \
+      cur_tap = rem ? __builtin_ctzll(rem) : 0;                                       \
+    }                                                                                 \
+  }
+#define FLM_STORE_ROW(J, RA, RB, OK)                                                                  \
+  {                                                                                                   \
+    const int row = r0 + 32 * J;                                                                      \
+    *reinterpret_cast<float4*>(As + sbuf * TILE_F + swz(row, c8)) = OK ? RA : make_float4(0.f, 0.f, 0.f, 0.f); \
+    *reinterpret_cast<float4*>(Bs + sbuf * TILE_F + swz(row, c8)) = RB;                               \
+  }
+#define FLM_STORE_LDS(BUF)                                                                            \
+  {                                                                                                   \
+    const int sbuf = (BUF);                                                                           \
+    FLM_STORE_ROW(0, ra0, rb0, ok0) FLM_STORE_ROW(1, ra1, rb1, ok1) FLM_STORE_ROW(2, ra2, rb2, ok2)   \
+    FLM_STORE_ROW(3, ra3, rb3, ok3)                                                                   \
+  }
 
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -162,15 +178,15 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (nit > 0) {
-    issue_loads();
-    store_lds(0);
+    FLM_ISSUE_LOADS()
+    FLM_STORE_LDS(0)
   }
   __syncthreads();
 
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
     const bool more = it + 1 < nit;
-    if (more) issue_loads();
+    if (more) FLM_ISSUE_LOADS()
     const float* Ab = As + buf * TILE_F;
     const float* Bb = Bs + buf * TILE_F;
 #pragma unroll
@@ -191,9 +207,14 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (more) store_lds(buf ^ 1);
+    if (more) FLM_STORE_LDS(buf ^ 1)
     __syncthreads();
   }
+
+#undef FLM_LOAD_A
+#undef FLM_ISSUE_LOADS
+#undef FLM_STORE_ROW
+#undef FLM_STORE_LDS
 
   // ---- epilogue: y = acc*scale + shift, ReLU, 2x2 max-pool (MMAP 1), store ---------------------
   // accumulator layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -266,6 +287,10 @@ int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
   const long long M = (long long)d.n * d.h * d.w;
   if (M <= 0 || M > (1ll << 30)) {
     set_error("igemm_f32: pixel count %lld out of range", M);
+    return FLM_ERR_SHAPE;
+  }
+  if ((long long)M * d.cin >= (1ll << 31) || (long long)d.coutpad * d.kh * d.kw * d.cin >= (1ll << 31)) {
+    set_error("igemm_f32: tensor exceeds 2^31 elements (split the batch)");
     return FLM_ERR_SHAPE;
   }
   IgemmArgs a;
