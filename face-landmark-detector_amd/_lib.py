@@ -22,7 +22,7 @@ EXPORTS = [
     "flm_abi_version", "flm_last_error",
     "flm_fcn8_packed_bytes", "flm_fcn8_pack",
     "flm_fcn8_workspace_bytes", "flm_fcn8_forward", "flm_fcn8_workspace_offset", "flm_fcn8_run_layer",
-    "flm_profile_enable", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
+    "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
     "flm_decode_workspace_bytes", "flm_decode",
     "flm_similarity_from_landmarks", "flm_warp_affine", "flm_crop_resize",
@@ -64,6 +64,10 @@ def _declare(lib):
     lib.flm_fcn8_workspace_offset.argtypes = [C.c_char_p] + [i] * 8
     lib.flm_fcn8_run_layer.restype = i
     lib.flm_fcn8_run_layer.argtypes = [vp, vp, C.c_char_p, vp, vp, i, i, i, i, i]
+    lib.flm_set_tuning.restype = i
+    lib.flm_set_tuning.argtypes = [C.c_char_p, i]
+    lib.flm_debug_query.restype = i
+    lib.flm_debug_query.argtypes = [C.c_char_p, i]
     lib.flm_profile_enable.restype = i
     lib.flm_profile_enable.argtypes = [i]
     lib.flm_profile_reset.restype = i

@@ -123,6 +123,20 @@ extern "C" {
 
 int flm_abi_version(void) { return FLM_ABI_VERSION; }
 
+int flm_debug_query(const char* key, int arg) {
+  if (key && !strcmp(key, "igemm_occupancy")) return igemm_occupancy((size_t)arg);
+  return -1;
+}
+
+int flm_set_tuning(const char* key, int value) {
+  if (!key) return FLM_ERR_ARG;
+  if (!strcmp(key, "igemm_stagger")) { g_igemm_stagger = value; return FLM_OK; }
+  if (!strcmp(key, "convt_stagger")) { g_convt_stagger = value; return FLM_OK; }
+  if (!strcmp(key, "igemm_debug")) { g_igemm_debug = value; return FLM_OK; }
+  set_error("flm_set_tuning: unknown key '%s'", key);
+  return FLM_ERR_ARG;
+}
+
 int flm_profile_enable(int max_records) {
   if (g_prof) return FLM_OK;
   if (max_records <= 0 || max_records > (1 << 20)) {

@@ -35,7 +35,10 @@ struct ConvTArgs {
   int n, hi, wi, ho, wo, s, ldy, epilogue;
   int C, Cp;
   int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
+  int stagger;  // start delay of the odd co-resident workgroup, x64 cycles
 };
+
+int g_convt_stagger = 120;  // x64 cycles (tunable through flm_set_tuning)
 
 constexpr int GCH = 6;  // k groups per LDS chunk
 
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
   }
 
   FLM_ISSUE(0)
+  stagger_odd_workgroup(a.stagger);
   FLM_STASH(0)
   __syncthreads();
 
@@ -268,6 +272,7 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     return FLM_ERR_SHAPE;
   }
   a.P = (int)P;
+  a.stagger = g_convt_stagger;
   if (d.epilogue == 0 && (d.ldy & 3)) {
     set_error("convt: raw epilogue needs a channel stride that is a multiple of 4");
     return FLM_ERR_SHAPE;

@@ -41,7 +41,12 @@ struct IgemmArgs {
   int K;        // kh*kw*cin
   int mtiles, ntiles;
   int cpt;      // 32-channel chunks per tap = cin/32
+  int stagger;  // start delay of the odd co-resident workgroup, x64 cycles
+  int dbg;      // diagnosis only (wrong results): 1 no global loads in loop, 2 no LDS writes, 4 no barrier
 };
+
+int g_igemm_debug = 0;
+int g_igemm_stagger = 40;  // x64 cycles (tunable through flm_set_tuning)
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_F = BM * BK;  // floats per operand tile
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
 
   if (nit > 0) {
     FLM_ISSUE_LOADS()
+    stagger_odd_workgroup(a.stagger);
     FLM_STORE_LDS(0)
   }
   __syncthreads();
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
     const bool more = it + 1 < nit;
-    if (more) FLM_ISSUE_LOADS()
+    if (more && !(a.dbg & 1)) FLM_ISSUE_LOADS()
     const float* Ab = As + buf * TILE_F;
     const float* Bb = Bs + buf * TILE_F;
 #pragma unroll
@@ -207,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (more) FLM_STORE_LDS(buf ^ 1)
-    __syncthreads();
+    if (more && !(a.dbg & 2)) FLM_STORE_LDS(buf ^ 1)
+    if (!(a.dbg & 4)) __syncthreads();
   }
 
 #undef FLM_LOAD_A
@@ -275,6 +281,14 @@ static int launch_t(hipStream_t s, const IgemmArgs& a) {
   return FLM_OK;
 }
 
+int igemm_occupancy(size_t lds_bytes) {
+  int nb = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&igemm_f32_kernel<0, true>), 256,
+                                                   lds_bytes) != hipSuccess)
+    return -1;
+  return nb;
+}
+
 int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
   if (d.cin % 32 != 0 || d.coutpad % BN != 0 || d.cout > d.coutpad || d.kh * d.kw > 64) {
     set_error("igemm_f32: unsupported shape cin=%d coutpad=%d cout=%d k=%dx%d", d.cin, d.coutpad, d.cout, d.kh, d.kw);
@@ -302,6 +316,8 @@ int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = d.coutpad / BN;
   a.cpt = d.cin / BK;
+  a.stagger = g_igemm_stagger;
+  a.dbg = g_igemm_debug;
   // only whole N tiles that hold stored columns are launched
   a.ntiles = cdiv(d.cout, BN);
   if (d.pool) return d.relu ? launch_t<1, true>(s, a) : launch_t<1, false>(s, a);
