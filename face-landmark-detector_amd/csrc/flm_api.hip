@@ -68,6 +68,8 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int out_mode, int decode_mode,
   W.score5 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * g.Cp);
   W.fuse4 = take(cur, sizeof(float) * (size_t)n * h4 * w4 * g.Cp);
   W.seg = take(cur, sizeof(float) * (size_t)n * h3 * w3 * g.Cp);
+  W.splitk_bytes = sizeof(float) * 8 * (size_t)n * h5 * w5 * g.Cp;
+  W.splitk = take(cur, W.splitk_bytes);
   W.oh = h + 8;
   W.ow = w + 8;
   W.probs = SIZE_MAX;
@@ -101,8 +103,10 @@ static int check_fcn8_shape(int n, int h, int w, int C, int dtype) {
 }
 
 static int conv_layer(hipStream_t s, const char* blob, const ConvPack& c, const float* x, float* y, int n, int h,
-                      int w, int relu, int pool, int posmajor) {
+                      int w, int relu, int pool, int posmajor, float* splitk_ws = nullptr, size_t splitk_bytes = 0) {
   IgemmDesc d;
+  d.splitk_ws = splitk_ws;
+  d.splitk_ws_bytes = splitk_bytes;
   d.x = x;
   d.wt = reinterpret_cast<const float*>(blob + c.w);
   d.scale = reinterpret_cast<const float*>(blob + c.scale);
@@ -284,7 +288,8 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
   rc = conv_layer(s, blob, L.fc7, fc6, fc7, n, h5, w5, 1, 0, 0); }
   if (rc) return rc;
   { ProfScope ps(s, "score5");
-  rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0); }
+  rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0, reinterpret_cast<float*>(ws + W.splitk),
+                  W.splitk_bytes); }
   if (rc) return rc;
   // skip branches: score4 on f4 -> fuse4 buffer, score3 on f3 -> seg buffer, then the transposed
   // convs add themselves onto those (crop keeps the top-left window, fcn.py:76-84)

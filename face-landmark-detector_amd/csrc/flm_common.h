@@ -66,6 +66,8 @@ Fcn8Pack fcn8_pack_layout(int C);
 struct Fcn8Ws {
   size_t f[5];
   size_t fc6, fc7, score5, fuse4, seg;
+  size_t splitk;  // split-K partial sums of the score convs
+  size_t splitk_bytes;
   size_t probs;   // logits/probs when they are not the call's output (else == SIZE_MAX)
   size_t decode;  // decode partials
   size_t total;
@@ -91,6 +93,8 @@ struct IgemmDesc {
   int ldc;      // channel stride of y
   int kh, kw, pad;
   int relu, pool, posmajor;
+  float* splitk_ws;        // optional scratch for split-K partial sums (null: never split)
+  size_t splitk_ws_bytes;
 };
 int launch_igemm_f32(hipStream_t s, const IgemmDesc& d);
 int igemm_occupancy(size_t lds_bytes);

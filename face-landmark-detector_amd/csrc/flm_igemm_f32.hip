@@ -19,9 +19,11 @@
 //   1  2x2 quads (n, y/2, x/2, y&1, x&1): the four rows of a max-pool window are registers
 //      4j..4j+3 of one lane in the 32x32 accumulator layout, so the pool is an in-lane max and
 //      the pooled pixel index is m>>2.
-//   2  position-major (y, x, n): a tile holds one or two spatial positions of many faces, so
-//      filter taps that fall outside the 8x8 map for the whole tile are skipped (fc6: 7x7 'same'
-//      on 8x8 -- 38 % of its dense MACs multiply zero padding).
+//   2  position-major (y, x, n): a tile holds one or two neighbouring spatial positions of many faces,
+//      so filter taps that fall outside the 8x8 map for the whole tile are skipped (fc6: 7x7 'same' on
+//      8x8 -- 38 % of its dense MACs multiply zero padding).  Tiles then differ in work (20..49 taps):
+//      every workgroup ranks the tiles by tap count (a few hundred integer ops) and runs the i-th
+//      heaviest and the i-th lightest back to back, so all workgroups carry about the same load.
 #include "flm_common.h"
 
 namespace flm {
@@ -42,7 +44,9 @@ struct IgemmArgs {
   int mtiles, ntiles;
   int cpt;      // 32-channel chunks per tap = cin/32
   int stagger;  // start delay of the odd co-resident workgroup, x64 cycles
-  int dbg;      // diagnosis only (wrong results): 1 no global loads in loop, 2 no LDS writes, 4 no barrier
+  int kw_magic; // ceil(65536 / kw): tap / kw == (tap * kw_magic) >> 16 for tap < 64
+  int ksplit;   // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to `part`
+  float* part;  // [ksplit][M][ldc]
 };
 
 int g_igemm_debug = 0;
@@ -50,6 +54,23 @@ int g_igemm_stagger = 40;  // x64 cycles (tunable through flm_set_tuning)
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_F = BM * BK;  // floats per operand tile
+
+// Taps of a kh x kw 'same' filter that touch at least one in-bounds pixel for m-tile t in
+// position-major order (positions t*BM/n .. of an h x w map): bit ky*kw+kx.
+__device__ __forceinline__ unsigned long long posmajor_tapmask(int t, int M, int n, int h, int w, int kh, int kw,
+                                                               int pad) {
+  const int m_lo = t * 128, m_hi = (m_lo + 128 < M ? m_lo + 128 : M) - 1;
+  unsigned long long mask = 0;
+  for (int p = m_lo / n; p <= m_hi / n; ++p) {
+    const int y = p / w, x = p % w;
+    for (int ky = 0; ky < kh; ++ky) {
+      if ((unsigned)(y + ky - pad) >= (unsigned)h) continue;
+      for (int kx = 0; kx < kw; ++kx)
+        if ((unsigned)(x + kx - pad) < (unsigned)w) mask |= 1ull << (ky * kw + kx);
+    }
+  }
+  return mask;
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
@@ -64,8 +85,34 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = L % a.mtiles, nt = L / a.mtiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  // MMAP 2: a workgroup owns the tile pair (i, MT-1-i); otherwise one tile
+  const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
+  const int mslot = L % mslots, nt = L / mslots;
+  const int n0 = nt * BN;
+  const int npass = (MMAP == 2 && mslot != a.mtiles - 1 - mslot) ? 2 : 1;
+  int pair_mt[2] = {mslot, mslot};
+  if (MMAP == 2) {
+    // rank the tiles by work, heaviest first (ties by index); LDS scratch = the still unused A buffer
+    int* wk = reinterpret_cast<int*>(As);
+    int* ord = wk + a.mtiles;
+    for (int t = tid; t < a.mtiles; t += 256)
+      wk[t] = __builtin_popcountll(posmajor_tapmask(t, a.M, a.n, a.h, a.w, a.kh, a.kw, a.pad));
+    __syncthreads();
+    for (int t = tid; t < a.mtiles; t += 256) {
+      const int wt = wk[t];
+      int rank = 0;
+      for (int u = 0; u < a.mtiles; ++u) rank += (wk[u] > wt) || (wk[u] == wt && u < t);
+      ord[rank] = t;
+    }
+    __syncthreads();
+    pair_mt[0] = ord[mslot];
+    pair_mt[1] = ord[a.mtiles - 1 - mslot];
+    __syncthreads();
+  }
+  for (int pass = 0; pass < npass; ++pass) {
+  const int mt = pair_mt[pass];
+  const int m0 = mt * BM;
+  if (pass) __syncthreads();  // the previous tile's last fragment reads are done before LDS is refilled
 
   // ---- staging role: rows r0+32j, 16-byte chunk c8 of the 128-byte k-run ----------------------
   const int c8 = tid & 7, r0 = tid >> 3;
@@ -116,7 +163,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
     const unsigned tm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tapmask >> 32));
     tapmask = ((unsigned long long)tm_hi << 32) | (unsigned long long)tm_lo;
   }
-  const int nit = __builtin_popcountll(tapmask) * a.cpt;
+  int nit = __builtin_popcountll(tapmask) * a.cpt;
+  int it_first = 0;
+  if (a.ksplit > 1) {  // 1x1 convs only (one tap): the k-steps are the channel chunks
+    it_first = (int)blockIdx.y * nit / a.ksplit;
+    nit = ((int)blockIdx.y + 1) * nit / a.ksplit - it_first;
+  }
 
   // per-row element offset of the centre pixel; per-tap displacement is wave-uniform
   unsigned rowoff[4];
@@ -126,104 +178,157 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) wrow[j] = a.wt + (size_t)(n0 + r0 + 32 * j) * a.K + 4 * c8;
 
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-  bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
+  // ---- software pipeline ---------------------------------------------------------------------------
+  // Step t computes tile t from LDS[t&1]; in the SAME step, spread between the 64 MFMAs, it issues the
+  // global loads of tile t+2 into one register set and writes tile t+1 (loaded during step t-1, so long
+  // landed) from the other set into LDS[(t+1)&1].  Every non-matrix instruction sits in the shadow of an
+  // MFMA (one 64-cycle MFMA holds the SIMD's issue port for a few cycles only), the wave never waits on
+  // memory it asked for less than a full step ago, and the only exposed window per step is the barrier
+  // plus the first fragment read.  Register sets are NAMED scalars (arrays under `if` go to scratch).
+  float4 ra0P, ra1P, ra2P, ra3P, rb0P, rb1P, rb2P, rb3P;
+  float4 ra0Q, ra1Q, ra2Q, ra3Q, rb0Q, rb1Q, rb2Q, rb3Q;
+  bool ok0P = false, ok1P = false, ok2P = false, ok3P = false;
+  bool ok0Q = false, ok1Q = false, ok2Q = false, ok3Q = false;
+  ra0P = ra1P = ra2P = ra3P = rb0P = rb1P = rb2P = rb3P = make_float4(0.f, 0.f, 0.f, 0.f);
+  ra0Q = ra1Q = ra2Q = ra3Q = rb0Q = rb1Q = rb2Q = rb3Q = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // iterator over (valid tap, channel chunk)
+  // iterator over (valid tap, channel chunk): state of the NEXT tile to load
   unsigned long long rem = tapmask;
   int cur_tap = __builtin_ctzll(rem);
-  int cur_chunk = 0;
+  int cur_chunk = it_first;
+  int ld_ky = 0, ld_kx = 0, ld_delta = 0, ld_koff = 0, ld_c0 = 0;
 
+#define FLM_TILE_PARAMS()                                                    \
+  {                                                                          \
+    const int ty = (cur_tap * a.kw_magic) >> 16;                             \
+    ld_ky = ty - a.pad;                                                      \
+    ld_kx = cur_tap - ty * a.kw - a.pad;                                     \
+    ld_delta = (ld_ky * a.w + ld_kx) * a.cin;                                \
+    ld_c0 = cur_chunk * BK;                                                  \
+    ld_koff = cur_tap * a.cin + ld_c0;                                       \
+    if (++cur_chunk == a.cpt) {                                              \
+      cur_chunk = 0;                                                         \
+      rem &= rem - 1;                                                        \
+      cur_tap = rem ? __builtin_ctzll(rem) : 0;                              \
+    }                                                                        \
+  }
   // Out-of-bounds rows load a valid address (their own centre pixel) and are zeroed at the LDS write,
-  // so the eight loads issue back to back with no branch around them.
-#define FLM_LOAD_A(J, RA, OK)                                                                        \
-  {                                                                                                  \
-    const int iy = py[J] + ky, ix = px[J] + kx;                                                      \
-    OK = pv[J] && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;                     \
-    const unsigned off = rowoff[J] + (OK ? (unsigned)tapdelta : 0u) + (unsigned)(cur_chunk * BK);  \
-    RA = *reinterpret_cast<const float4*>(a.x + off);                                                \
+  // so loads issue with no branch around them.
+#define FLM_LOAD_A(J, RA, OK)                                                                  \
+  {                                                                                            \
+    const int iy = py[J] + ld_ky, ix = px[J] + ld_kx;                                          \
+    OK = pv[J] && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;               \
+    const unsigned off = rowoff[J] + (OK ? (unsigned)ld_delta : 0u) + (unsigned)ld_c0;         \
+    RA = *reinterpret_cast<const float4*>(a.x + off);                                          \
   }
-#define FLM_ISSUE_LOADS()                                                             \
-  {                                                                                   \
-    const int ky = cur_tap / a.kw - a.pad, kx = cur_tap % a.kw - a.pad;               \
-    const int tapdelta = (ky * a.w + kx) * a.cin;                                     \
-    const int koff = cur_tap * a.cin + cur_chunk * BK;                                \
-    FLM_LOAD_A(0, ra0, ok0) FLM_LOAD_A(1, ra1, ok1) FLM_LOAD_A(2, ra2, ok2) FLM_LOAD_A(3, ra3, ok3) \
-    rb0 = *reinterpret_cast<const float4*>(wrow[0] + koff);                           \
-    rb1 = *reinterpret_cast<const float4*>(wrow[1] + koff);                           \
-    rb2 = *reinterpret_cast<const float4*>(wrow[2] + koff);                           \
-    rb3 = *reinterpret_cast<const float4*>(wrow[3] + koff);                           \
-    if (++cur_chunk == a.cpt) {                                                       \
-      cur_chunk = 0;                                                                  \
-      rem &= rem - 1;                                                                 \
-      cur_tap = rem ? __builtin_ctzll(rem) : 0;                                       \
-    }                                                                                 \
-  }
-#define FLM_STORE_ROW(J, RA, RB, OK)                                                                  \
-  {                                                                                                   \
-    const int row = r0 + 32 * J;                                                                      \
-    *reinterpret_cast<float4*>(As + sbuf * TILE_F + swz(row, c8)) = OK ? RA : make_float4(0.f, 0.f, 0.f, 0.f); \
-    *reinterpret_cast<float4*>(Bs + sbuf * TILE_F + swz(row, c8)) = RB;                               \
-  }
-#define FLM_STORE_LDS(BUF)                                                                            \
-  {                                                                                                   \
-    const int sbuf = (BUF);                                                                           \
-    FLM_STORE_ROW(0, ra0, rb0, ok0) FLM_STORE_ROW(1, ra1, rb1, ok1) FLM_STORE_ROW(2, ra2, rb2, ok2)   \
-    FLM_STORE_ROW(3, ra3, rb3, ok3)                                                                   \
-  }
+#define FLM_LOAD_B(J, RB) RB = *reinterpret_cast<const float4*>(wrow[J] + ld_koff);
+#define FLM_STORE_A(J, RA, OK) \
+  *reinterpret_cast<float4*>(As + sbuf * TILE_F + swz(r0 + 32 * J, c8)) = OK ? RA : make_float4(0.f, 0.f, 0.f, 0.f);
+#define FLM_STORE_B(J, RB) *reinterpret_cast<float4*>(Bs + sbuf * TILE_F + swz(r0 + 32 * J, c8)) = RB;
 
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // fragment read offsets (floats): rows 64*wr + 32*i + lr of A, 64*wc + 32*j + lr of B; the XOR term of
+  // the swizzle depends on lr only, the chunk is 2*t + lh
+  const int swx = (lr >> 1) & 7;
+  const int fa0 = (64 * wr + lr) * BK, fa1 = fa0 + 32 * BK;
+  const int fb0 = (64 * wc + lr) * BK, fb1 = fb0 + 32 * BK;
+  const int fc0 = ((0 + lh) ^ swx) << 2, fc1 = ((2 + lh) ^ swx) << 2, fc2 = ((4 + lh) ^ swx) << 2,
+            fc3 = ((6 + lh) ^ swx) << 2;
 
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+
+#define FLM_READ_FRAGS(AF0, AF1, BF0, BF1, FC)                                   \
+  AF0 = *reinterpret_cast<const float4*>(Ab + fa0 + FC);                         \
+  AF1 = *reinterpret_cast<const float4*>(Ab + fa1 + FC);                         \
+  BF0 = *reinterpret_cast<const float4*>(Bb + fb0 + FC);                         \
+  BF1 = *reinterpret_cast<const float4*>(Bb + fb1 + FC);
+#define FLM_MFMA4(AF0, AF1, BF0, BF1, E)                                         \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF0.E, BF0.E, acc00, 0, 0, 0);    \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF0.E, BF1.E, acc01, 0, 0, 0);    \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF1.E, BF0.E, acc10, 0, 0, 0);    \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF1.E, BF1.E, acc11, 0, 0, 0);    \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // One step.  W* = register set written to LDS now (tile it+1), L* = set receiving the loads of tile it+2.
+  // No branches inside a step (hipcc drops to `s_waitcnt vmcnt(0)` in front of every load and LDS write
+  // that sits in its own basic block): past the last tile the loads re-read tile (tap 0, chunk 0) and the
+  // writes refill a buffer nobody reads any more.
+#define FLM_STEP(IT, W, L)                                                                            \
+  {                                                                                                   \
+    const int it_ = (IT);                                                                             \
+    const int buf = it_ & 1, sbuf = buf ^ 1;                                                          \
+    const float* Ab = As + buf * TILE_F;                                                              \
+    const float* Bb = Bs + buf * TILE_F;                                                              \
+    float4 afx0, afx1, bfx0, bfx1, afy0, afy1, bfy0, bfy1;                                            \
+    FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, fc0)                                                       \
+    FLM_TILE_PARAMS()                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    /* group 0: loads of A rows */                                                                    \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, x) FLM_READ_FRAGS(afy0, afy1, bfy0, bfy1, fc1)                  \
+    FLM_LOAD_A(0, ra0##L, ok0##L)                                                            \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y) FLM_LOAD_A(1, ra1##L, ok1##L)                       \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z) FLM_LOAD_A(2, ra2##L, ok2##L)                       \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w) FLM_LOAD_A(3, ra3##L, ok3##L)                       \
+    /* group 1: loads of B rows */                                                                    \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, x) FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, fc2)                  \
+    FLM_LOAD_B(0, rb0##L)                                                                    \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_LOAD_B(1, rb1##L)                               \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_LOAD_B(2, rb2##L)                               \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_LOAD_B(3, rb3##L)                               \
+    /* group 2: LDS writes of tile it+1, A rows */                                                    \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, x) FLM_READ_FRAGS(afy0, afy1, bfy0, bfy1, fc3)                  \
+    FLM_STORE_A(0, ra0##W, ok0##W)                                                           \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y) FLM_STORE_A(1, ra1##W, ok1##W)                      \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z) FLM_STORE_A(2, ra2##W, ok2##W)                      \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w) FLM_STORE_A(3, ra3##W, ok3##W)                      \
+    /* group 3: LDS writes, B rows */                                                                 \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, x) FLM_STORE_B(0, rb0##W)                              \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_STORE_B(1, rb1##W)                              \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_STORE_B(2, rb2##W)                              \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_STORE_B(3, rb3##W)                              \
+    __syncthreads();                                                                                  \
+  }
+
+  // prologue: tile 0 -> set P -> LDS[0]; tile 1 -> set Q (written during step 0)
   if (nit > 0) {
-    FLM_ISSUE_LOADS()
-    stagger_odd_workgroup(a.stagger);
-    FLM_STORE_LDS(0)
+    FLM_TILE_PARAMS()
+    FLM_LOAD_A(0, ra0P, ok0P) FLM_LOAD_A(1, ra1P, ok1P) FLM_LOAD_A(2, ra2P, ok2P) FLM_LOAD_A(3, ra3P, ok3P)
+    FLM_LOAD_B(0, rb0P) FLM_LOAD_B(1, rb1P) FLM_LOAD_B(2, rb2P) FLM_LOAD_B(3, rb3P)
+    if (nit > 1) {
+      FLM_TILE_PARAMS()
+      FLM_LOAD_A(0, ra0Q, ok0Q) FLM_LOAD_A(1, ra1Q, ok1Q) FLM_LOAD_A(2, ra2Q, ok2Q) FLM_LOAD_A(3, ra3Q, ok3Q)
+      FLM_LOAD_B(0, rb0Q) FLM_LOAD_B(1, rb1Q) FLM_LOAD_B(2, rb2Q) FLM_LOAD_B(3, rb3Q)
+    }
+    {
+      const int sbuf = 0;
+      FLM_STORE_A(0, ra0P, ok0P) FLM_STORE_A(1, ra1P, ok1P) FLM_STORE_A(2, ra2P, ok2P) FLM_STORE_A(3, ra3P, ok3P)
+      FLM_STORE_B(0, rb0P) FLM_STORE_B(1, rb1P) FLM_STORE_B(2, rb2P) FLM_STORE_B(3, rb3P)
+    }
   }
   __syncthreads();
 
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    const bool more = it + 1 < nit;
-    if (more && !(a.dbg & 1)) FLM_ISSUE_LOADS()
-    const float* Ab = As + buf * TILE_F;
-    const float* Bb = Bs + buf * TILE_F;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float4 af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const float4*>(Ab + swz(64 * wr + 32 * i + lr, 2 * t + lh));
-        bf[i] = *reinterpret_cast<const float4*>(Bb + swz(64 * wc + 32 * i + lr, 2 * t + lh));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (more && !(a.dbg & 2)) FLM_STORE_LDS(buf ^ 1)
-    if (!(a.dbg & 4)) __syncthreads();
+  // step it writes set Q (tile it+1) and loads tile it+2 into set P; the next step swaps the roles
+  for (int it = 0; it < nit; it += 2) {
+    FLM_STEP(it, Q, P)
+    if (it + 1 < nit) FLM_STEP(it + 1, P, Q)
   }
 
+#undef FLM_TILE_PARAMS
 #undef FLM_LOAD_A
-#undef FLM_ISSUE_LOADS
-#undef FLM_STORE_ROW
-#undef FLM_STORE_LDS
+#undef FLM_LOAD_B
+#undef FLM_STORE_A
+#undef FLM_STORE_B
+#undef FLM_READ_FRAGS
+#undef FLM_MFMA4
+#undef FLM_STEP
 
   // ---- epilogue: y = acc*scale + shift, ReLU, 2x2 max-pool (MMAP 1), store ---------------------
   // accumulator layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  f32x16 acc[2][2];
+  acc[0][0] = acc00; acc[0][1] = acc01; acc[1][0] = acc10; acc[1][1] = acc11;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 64 * wc + 32 * j + lr;
@@ -251,6 +356,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
           const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float u = fmaf(acc[i][j][r], sc, sh);
           if (RELU) u = fmaxf(u, 0.f);
+          if (a.ksplit > 1) {
+            if (cok && m < a.M) a.part[((size_t)blockIdx.y * a.M + m) * a.ldc + col] = acc[i][j][r];
+            continue;
+          }
           if (cok && m < a.M) {
             size_t orow;
             if (MMAP == 2) {
@@ -265,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
       }
     }
   }
+  }  // pass
 }
 
 template <int MMAP, bool RELU>
@@ -276,9 +386,26 @@ static int launch_t(hipStream_t s, const IgemmArgs& a) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  igemm_f32_kernel<MMAP, RELU><<<a.mtiles * a.ntiles, 256, lds, s>>>(a);
+  const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
+  igemm_f32_kernel<MMAP, RELU><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
   FLM_LAUNCH_CHECK("igemm_f32_kernel");
   return FLM_OK;
+}
+
+// y[m][c] = act(scale[c] * sum_s part[s][m][c] + shift[c]); fixed summation order (deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ y, int M, int ldc, int cout,
+                                     int ksplit, int relu) {
+  const size_t total = (size_t)M * ldc;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldc);
+    if (c >= cout) continue;
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += part[(size_t)s * total + i];
+    v = fmaf(v, scale[c], shift[c]);
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
 }
 
 int igemm_occupancy(size_t lds_bytes) {
@@ -317,12 +444,31 @@ int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
   a.ntiles = d.coutpad / BN;
   a.cpt = d.cin / BK;
   a.stagger = g_igemm_stagger;
-  a.dbg = g_igemm_debug;
+  a.kw_magic = (65536 + d.kw - 1) / d.kw;
+  // split-K for 1x1 layers whose tile grid cannot fill the chip (score5: 32 workgroups, 128 k-steps)
+  a.ksplit = 1;
+  a.part = nullptr;
+  const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
+  if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && tiles <= 64 && a.cpt >= 32) {
+    int ks = 256 / tiles;
+    if (ks > 8) ks = 8;
+    if (ks > a.cpt / 8) ks = a.cpt / 8;
+    if (ks > 1 && (size_t)ks * a.M * d.ldc * sizeof(float) <= d.splitk_ws_bytes) {
+      a.ksplit = ks;
+      a.part = d.splitk_ws;
+    }
+  }
   // only whole N tiles that hold stored columns are launched
   a.ntiles = cdiv(d.cout, BN);
   if (d.pool) return d.relu ? launch_t<1, true>(s, a) : launch_t<1, false>(s, a);
   if (d.posmajor) return d.relu ? launch_t<2, true>(s, a) : launch_t<2, false>(s, a);
-  return d.relu ? launch_t<0, true>(s, a) : launch_t<0, false>(s, a);
+  int rc = d.relu ? launch_t<0, true>(s, a) : launch_t<0, false>(s, a);
+  if (rc || a.ksplit <= 1) return rc;
+  const size_t total = (size_t)a.M * d.ldc;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, a.y, a.M, d.ldc, d.cout, a.ksplit, d.relu);
+  FLM_LAUNCH_CHECK("splitk_reduce_kernel");
+  return FLM_OK;
 }
 
 }  // namespace flm
