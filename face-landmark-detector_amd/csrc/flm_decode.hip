@@ -95,28 +95,53 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
   }
 
   const int tile_f = PT * L;  // floats per full tile (multiple of 4 because PT is)
+  // Register prefetch of the NEXT tile (named registers: up to 6 x 16 bytes per thread cover L <= 96),
+  // issued before the current tile is processed so the HBM latency hides behind the selection work.
+  float4 pf0, pf1, pf2, pf3, pf4, pf5;
+  pf0 = pf1 = pf2 = pf3 = pf4 = pf5 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define FLM_PF_LOAD(I, R)                                                         \
+  {                                                                               \
+    const int e4 = tid * 4 + 1024 * I;                                            \
+    if (e4 < tile_f) R = *reinterpret_cast<const float4*>(nsrc + e4);             \
+  }
+#define FLM_PF_STORE(I, R)                                                        \
+  {                                                                               \
+    const int e4 = tid * 4 + 1024 * I;                                            \
+    if (e4 < tile_f) {                                                            \
+      int p = e4 / L, c = e4 - p * L;                                             \
+      tile[p * LS + c] = R.x; if (++c == L) { c = 0; ++p; }                       \
+      tile[p * LS + c] = R.y; if (++c == L) { c = 0; ++p; }                       \
+      tile[p * LS + c] = R.z; if (++c == L) { c = 0; ++p; }                       \
+      tile[p * LS + c] = R.w;                                                     \
+    }                                                                             \
+  }
+  bool pf_valid = false;
+  if (a.vec && p_begin + PT <= p_end) {
+    const float* nsrc = src + (size_t)p_begin * L;
+    FLM_PF_LOAD(0, pf0) FLM_PF_LOAD(1, pf1) FLM_PF_LOAD(2, pf2) FLM_PF_LOAD(3, pf3) FLM_PF_LOAD(4, pf4)
+    FLM_PF_LOAD(5, pf5)
+    pf_valid = true;
+  }
   for (int p0 = p_begin; p0 < p_end; p0 += PT) {
     const int npx = min(PT, p_end - p0);
     const int nf = npx * L;
     __syncthreads();
-    // ---- stage: 16-byte coalesced loads, scatter into the odd-stride LDS image -------------------
-    const float* tsrc = src + (size_t)p0 * L;
-    for (int e4 = tid * 4; e4 < tile_f; e4 += 256 * 4) {
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.vec && e4 + 3 < nf) {
-        const float4 t = *reinterpret_cast<const float4*>(tsrc + e4);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (e4 + i < nf) v[i] = tsrc[e4 + i];
+    if (pf_valid) {
+      FLM_PF_STORE(0, pf0) FLM_PF_STORE(1, pf1) FLM_PF_STORE(2, pf2) FLM_PF_STORE(3, pf3) FLM_PF_STORE(4, pf4)
+      FLM_PF_STORE(5, pf5)
+    } else {
+      // partial or unaligned tile: plain loads, zero fill
+      const float* tsrc = src + (size_t)p0 * L;
+      for (int e = tid; e < tile_f; e += 256) {
+        const int p = e / L, c = e - p * L;
+        tile[p * LS + c] = (e < nf) ? tsrc[e] : 0.f;
       }
-      int p = e4 / L, c = e4 - p * L;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (e4 + i < tile_f) tile[p * LS + c] = v[i];
-        if (++c == L) { c = 0; ++p; }
-      }
+    }
+    pf_valid = a.vec && p0 + 2 * PT <= p_end;
+    if (pf_valid) {
+      const float* nsrc = src + (size_t)(p0 + PT) * L;
+      FLM_PF_LOAD(0, pf0) FLM_PF_LOAD(1, pf1) FLM_PF_LOAD(2, pf2) FLM_PF_LOAD(3, pf3) FLM_PF_LOAD(4, pf4)
+      FLM_PF_LOAD(5, pf5)
     }
     __syncthreads();
 
@@ -147,6 +172,9 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
       }
     }
   }
+
+#undef FLM_PF_LOAD
+#undef FLM_PF_STORE
 
   // ---- write partials ---------------------------------------------------------------------------
   if (MODE == FLM_DECODE_ALL) {
