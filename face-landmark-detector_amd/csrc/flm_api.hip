@@ -134,9 +134,8 @@ int flm_debug_query(const char* key, int arg) {
 
 int flm_set_tuning(const char* key, int value) {
   if (!key) return FLM_ERR_ARG;
-  if (!strcmp(key, "igemm_stagger")) { g_igemm_stagger = value; return FLM_OK; }
-  if (!strcmp(key, "convt_stagger")) { g_convt_stagger = value; return FLM_OK; }
-  if (!strcmp(key, "igemm_debug")) { g_igemm_debug = value; return FLM_OK; }
+  (void)value;  // no knobs are wired at the moment; the entry point stays for tools/tune.py
+  if (!strcmp(key, "none")) return FLM_OK;
   set_error("flm_set_tuning: unknown key '%s'", key);
   return FLM_ERR_ARG;
 }

@@ -124,8 +124,6 @@ int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, in
 int launch_crop_resize(hipStream_t s, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,
                        uint8_t* out, int oh, int ow);
 
-extern int g_igemm_stagger, g_convt_stagger, g_igemm_debug;
-
 // Bijective XCD-aware remap of a 1-D grid: blocks that the dispatcher deals to the same XCD
 // (b % 8) receive consecutive logical ids, so neighbours in logical order share an L2.
 __device__ __forceinline__ int xcd_remap(int b, int nblk) {
@@ -134,31 +132,5 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + loc;
 }
-
-// ---- start-time stagger of co-resident workgroups --------------------------------------------------
-// Two workgroups of the same MFMA kernel that share a CU start in the same cycle and then stay in
-// lockstep: both are in their matrix phase together (sharing the SIMD's MFMA pipe) and in their
-// non-matrix window (LDS refill + barrier, or a VALU epilogue) together, so the windows add to the
-// run time instead of hiding behind the other workgroup's MFMAs (measured: 2 x ~1000 idle pipe
-// cycles per 8192-cycle k-step in igemm, 2 x ~5000 per phase pair in convt).  One lane per workgroup
-// draws an arrival ticket for its CU (a monotonic counter per (XCC, SE, SH, CU); only the parity is
-// used, so it never needs a reset) and the odd arrival sleeps `sleep64` x 64 cycles before its
-// first barrier.  Placement only changes speed, never results.
-#ifdef __HIPCC__
-// one copy per translation unit (no relocatable device code): each kernel family counts on its own
-static __device__ unsigned g_cu_arrivals[16 * 256];
-
-__device__ __forceinline__ void stagger_odd_workgroup(int sleep64) {
-  if (threadIdx.x == 0) {
-    // s_getreg_b32 simm16 = (size-1) << 11 | offset << 6 | id
-    const unsigned cu = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);    // HW_REG_HW_ID[15:8]: cu, sh, se
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
-    const unsigned ticket = atomicAdd(&g_cu_arrivals[((xcc & 15u) << 8) | (cu & 255u)], 1u);
-    if (ticket & 1u) {
-      for (int left = sleep64; left > 0; left -= 8) __builtin_amdgcn_s_sleep(8);  // 8 x 64 cycles per turn
-    }
-  }
-}
-#endif
 
 }  // namespace flm

@@ -35,15 +35,12 @@ struct ConvTArgs {
   int n, hi, wi, ho, wo, s, ldy, epilogue;
   int C, Cp;
   int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
-  int stagger;  // start delay of the odd co-resident workgroup, x64 cycles
 };
-
-int g_convt_stagger = 120;  // x64 cycles (tunable through flm_set_tuning)
 
 constexpr int GCH = 6;  // k groups per LDS chunk
 
 template <int MT, int G>
-__global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
+__global__ __launch_bounds__(256, (MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
   constexpr int NCH = (G + GCH - 1) / GCH;
   constexpr int CHUNK_F4 = GCH * MT * 64;             // float4 per full chunk
   constexpr int NLD = (CHUNK_F4 + 255) / 256;         // staging loads per thread
@@ -110,9 +107,95 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
   }
 
   FLM_ISSUE(0)
-  stagger_odd_workgroup(a.stagger);
   FLM_STASH(0)
   __syncthreads();
+
+  // ---- phase loop with a software-pipelined epilogue ------------------------------------------------
+  // The epilogue of phase b0-1 (softmax: 20 exp + reductions + stores per lane at C=68) is cut in three
+  // parts that are issued INSIDE the MFMA stream of phase b0 (one part per weight chunk), so its VALU
+  // work runs in the shadow of the matrix pipe instead of after it.
+  //   part 1: class maximum (in-lane + two xor-shuffles), e = exp(x - max)
+  //   part 2: sum, one reciprocal, p = e * (1/sum)
+  //   part 3: stores (probabilities / class map / raw + skip)
+  f32x4 pv[MT];  // previous phase's accumulator, transformed in place by the parts
+#pragma unroll
+  for (int m = 0; m < MT; ++m) pv[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float p_mx = 0.f;
+
+#define FLM_EPI_PART1()                                                                           \
+  if (a.epilogue != 0) {                                                                          \
+    float mx = -3.402823466e38f;                                                                  \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
+      if (16 * m + 4 * q + e < a.C) mx = fmaxf(mx, pv[m][e]);                                     \
+    mx = fmaxf(mx, __shfl_xor(mx, 16));                                                           \
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                           \
+    p_mx = mx;                                                                                    \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
+      pv[m][e] = (16 * m + 4 * q + e < a.C) ? expf(pv[m][e] - mx) : 0.f;                          \
+  }
+#define FLM_EPI_PART2()                                                                           \
+  if (a.epilogue != 0) {                                                                          \
+    float sum = 0.f;                                                                              \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
+      sum += pv[m][e];                                                                            \
+    sum += __shfl_xor(sum, 16);                                                                   \
+    sum += __shfl_xor(sum, 32);                                                                   \
+    const float rs = 1.0f / sum;                                                                  \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
+      pv[m][e] = pv[m][e] * rs;                                                                   \
+  }
+#define FLM_EPI_PART3(B0)                                                                         \
+  {                                                                                               \
+    const int oy = s * i0 + a0, ox = s * j0 + (B0);                                               \
+    const bool ovalid = pvalid && oy < a.ho && ox < a.wo;                                         \
+    const size_t opix = ((size_t)img * a.ho + oy) * a.wo + ox;                                    \
+    if (a.epilogue == 0) {                                                                        \
+      if (ovalid) {                                                                               \
+        float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;                                  \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                          \
+          const int c4 = 16 * m + 4 * q;                                                          \
+          if (c4 < a.ldy) { /* ldy is a multiple of 4 here (score buffers, Cp channels) */        \
+            float4 v = make_float4(pv[m][0], pv[m][1], pv[m][2], pv[m][3]);                       \
+            if (a.skip) {                                                                         \
+              const float4 sk = *reinterpret_cast<const float4*>(a.skip + opix * a.Cp + c4);     \
+              v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;                                 \
+            }                                                                                     \
+            *reinterpret_cast<float4*>(y + c4) = v;                                               \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    } else if (a.epilogue == 1) {                                                                 \
+      if (ovalid) {                                                                               \
+        float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;                                  \
+        if ((a.ldy & 3) == 0) {                                                                   \
+          _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                        \
+            const int c4 = 16 * m + 4 * q;                                                        \
+            if (c4 < a.C)                                                                         \
+              *reinterpret_cast<float4*>(y + c4) = make_float4(pv[m][0], pv[m][1], pv[m][2], pv[m][3]); \
+          }                                                                                       \
+        } else {                                                                                  \
+          _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+            const int c = 16 * m + 4 * q + e;                                                     \
+            if (c < a.C) y[c] = pv[m][e];                                                         \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    } else {                                                                                      \
+      /* argmax over classes, first maximum wins (numpy argmax, prediction.py:209) */             \
+      float bv = -1.f;                                                                            \
+      int bi = 0x7fffffff;                                                                        \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+        const int c = 16 * m + 4 * q + e; /* ascending within a lane */                           \
+        if (c < a.C && pv[m][e] > bv) { bv = pv[m][e]; bi = c; }                                  \
+      }                                                                                           \
+      _Pragma("unroll") for (int sh = 16; sh <= 32; sh <<= 1) {                                   \
+        const float ov = __shfl_xor(bv, sh);                                                      \
+        const int oi = __shfl_xor(bi, sh);                                                        \
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }                               \
+      }                                                                                           \
+      if (ovalid && q == 0) reinterpret_cast<int*>(a.y)[opix] = bi;                               \
+    }                                                                                             \
+  }
 
   int seq = 0;
   for (int b0 = 0; b0 < s; ++b0) {
@@ -125,6 +208,12 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
       const bool more = seq + 1 < total;
       if (more) FLM_ISSUE(seq + 1)
       const float4* wl = lds + (seq & 1) * CHUNK_F4;
+      // epilogue part of the PREVIOUS phase, issued alongside this chunk's MFMAs
+      if (b0 > 0) {
+        if (ch == 0) FLM_EPI_PART1()
+        if (ch == (NCH > 1 ? 1 : 0)) FLM_EPI_PART2()
+        if (ch == NCH - 1) FLM_EPI_PART3(b0 - 1)
+      }
 #pragma unroll
       for (int gl = 0; gl < GCH; ++gl) {
         const int g = ch * GCH + gl;  // compile-time
@@ -146,100 +235,19 @@ __global__ __launch_bounds__(256, 2) void convt_kernel(ConvTArgs a) {
       __syncthreads();
       ++seq;
     }
-
-    // ---- epilogue for output pixel (s*i0+a0, s*j0+b0): lane holds classes 16m + 4q + e ------------
-    const int oy = s * i0 + a0, ox = s * j0 + b0;
-    const bool ovalid = pvalid && oy < a.ho && ox < a.wo;
-    const size_t opix = ((size_t)img * a.ho + oy) * a.wo + ox;
-    if (a.epilogue == 0) {
-      if (ovalid) {
-        float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int c4 = 16 * m + 4 * q;
-          if (c4 < a.ldy) {  // ldy is a multiple of 4 here (score buffers, Cp channels)
-            float4 v = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-            if (a.skip) {
-              const float4 sk = *reinterpret_cast<const float4*>(a.skip + opix * a.Cp + c4);
-              v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
-            }
-            *reinterpret_cast<float4*>(y + c4) = v;
-          }
-        }
-      }
-    } else {
-      // softmax over the C classes of this pixel (networks/utils.py:30), max-subtracted
-      float mx = -3.402823466e38f;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (16 * m + 4 * q + e < a.C) mx = fmaxf(mx, acc[m][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      float sum = 0.f;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ex = (16 * m + 4 * q + e < a.C) ? expf(acc[m][e] - mx) : 0.f;
-          acc[m][e] = ex;
-          sum += ex;
-        }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[m][e] = acc[m][e] / sum;
-      if (a.epilogue == 1) {
-        if (ovalid) {
-          float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;
-          if ((a.ldy & 3) == 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              const int c4 = 16 * m + 4 * q;
-              if (c4 < a.C) *reinterpret_cast<float4*>(y + c4) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-            }
-          } else {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int c = 16 * m + 4 * q + e;
-                if (c < a.C) y[c] = acc[m][e];
-              }
-          }
-        }
-      } else {
-        // argmax over classes, first maximum wins (numpy argmax, prediction.py:209)
-        float bv = -1.f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = 16 * m + 4 * q + e;  // ascending within a lane
-            if (c < a.C && acc[m][e] > bv) {
-              bv = acc[m][e];
-              bi = c;
-            }
-          }
-#pragma unroll
-        for (int sh = 16; sh <= 32; sh <<= 1) {
-          const float ov = __shfl_xor(bv, sh);
-          const int oi = __shfl_xor(bi, sh);
-          if (ov > bv || (ov == bv && oi < bi)) {
-            bv = ov;
-            bi = oi;
-          }
-        }
-        if (ovalid && q == 0) reinterpret_cast<int*>(a.y)[opix] = bi;
-      }
-    }
+    for (int m = 0; m < MT; ++m) pv[m] = acc[m];
   }
+  // drain: the last phase's epilogue
+  FLM_EPI_PART1()
+  FLM_EPI_PART2()
+  FLM_EPI_PART3(s - 1)
+  (void)p_mx;
 }
 
+#undef FLM_EPI_PART1
+#undef FLM_EPI_PART2
+#undef FLM_EPI_PART3
 #undef FLM_ISSUE
 #undef FLM_STASH
 #undef FLM_FOR_ST
@@ -272,7 +280,6 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     return FLM_ERR_SHAPE;
   }
   a.P = (int)P;
-  a.stagger = g_convt_stagger;
   if (d.epilogue == 0 && (d.ldy & 3)) {
     set_error("convt: raw epilogue needs a channel stride that is a multiple of 4");
     return FLM_ERR_SHAPE;

@@ -30,7 +30,7 @@ struct DecodeArgs {
   int mode, n_points;
   int vec;  // face stride is a multiple of 16 bytes: 16-byte loads allowed
   float thresh;
-  void* part;   // ALL: double [n][chunks][l][3]; TOPN: u64 [n][chunks][l][64]
+  void* part;   // ALL: double [n][chunks][l][3]; TOPN: u64 [n][chunks][l][n_points]
   double* out;  // [n][l][2]
 };
 
@@ -199,11 +199,11 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
     }
   } else {
     unsigned long long* part =
-        reinterpret_cast<unsigned long long*>(a.part) + ((size_t)face * a.chunks + chunk) * L * 64;
+        reinterpret_cast<unsigned long long*>(a.part) + ((size_t)face * a.chunks + chunk) * L * a.n_points;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = c_first + i;
-      if (c < L) part[(size_t)c * 64 + lane] = list[i];
+      if (c < L && lane < a.n_points) part[(size_t)c * a.n_points + lane] = list[i];
     }
   }
 }
@@ -232,10 +232,14 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
     out[1] = y;
   } else {
     const unsigned long long* part =
-        reinterpret_cast<const unsigned long long*>(a.part) + (size_t)face * a.chunks * L * 64;
+        reinterpret_cast<const unsigned long long*>(a.part) + (size_t)face * a.chunks * L * a.n_points;
     unsigned long long list = 0ull, tau = 0ull;
-    for (int s = 0; s < a.chunks; ++s) {
-      const unsigned long long cand = part[((size_t)s * L + c) * 64 + lane];
+    // 64 / n_points chunk lists are merged per pass (lane -> (chunk offset, rank))
+    const int per = 64 / a.n_points;
+    for (int s0 = 0; s0 < a.chunks; s0 += per) {
+      const int s = s0 + lane / a.n_points, rk = lane % a.n_points;
+      const unsigned long long cand =
+          (lane < per * a.n_points && s < a.chunks) ? part[((size_t)s * L + c) * a.n_points + rk] : 0ull;
       if (__any(cand > tau)) insert_candidates(list, tau, cand, a.n_points, lane);
     }
     // utils/metrics.py:69-77: ascending value order = list lanes n-1 .. 0
@@ -273,7 +277,8 @@ static void decode_plan(int n, int h, int w, int* chunks, int* chunk_px) {
 size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points) {
   int chunks, chunk_px;
   decode_plan(n, h, w, &chunks, &chunk_px);
-  const size_t per = (mode == FLM_DECODE_ALL) ? sizeof(double) * 3 : sizeof(unsigned long long) * 64;
+  const size_t per = (mode == FLM_DECODE_ALL) ? sizeof(double) * 3
+                                              : sizeof(unsigned long long) * (n_points > 0 ? n_points : 1);
   return align_up((size_t)n * chunks * l * per, 256);
 }
 

@@ -43,14 +43,10 @@ struct IgemmArgs {
   int K;        // kh*kw*cin
   int mtiles, ntiles;
   int cpt;      // 32-channel chunks per tap = cin/32
-  int stagger;  // start delay of the odd co-resident workgroup, x64 cycles
   int kw_magic; // ceil(65536 / kw): tap / kw == (tap * kw_magic) >> 16 for tap < 64
   int ksplit;   // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to `part`
   float* part;  // [ksplit][M][ldc]
 };
-
-int g_igemm_debug = 0;
-int g_igemm_stagger = 40;  // x64 cycles (tunable through flm_set_tuning)
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_F = BM * BK;  // floats per operand tile
@@ -163,12 +159,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
     const unsigned tm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tapmask >> 32));
     tapmask = ((unsigned long long)tm_hi << 32) | (unsigned long long)tm_lo;
   }
-  int nit = __builtin_popcountll(tapmask) * a.cpt;
-  int it_first = 0;
-  if (a.ksplit > 1) {  // 1x1 convs only (one tap): the k-steps are the channel chunks
-    it_first = (int)blockIdx.y * nit / a.ksplit;
-    nit = ((int)blockIdx.y + 1) * nit / a.ksplit - it_first;
+  int chunk_first = 0, chunk_end = a.cpt;
+  if (a.ksplit > 1) {  // split-K: blockIdx.y owns a contiguous range of channel chunks
+    chunk_first = (int)blockIdx.y * a.cpt / a.ksplit;
+    chunk_end = ((int)blockIdx.y + 1) * a.cpt / a.ksplit;
   }
+  const int nit = __builtin_popcountll(tapmask) * (chunk_end - chunk_first);
 
   // per-row element offset of the centre pixel; per-tap displacement is wave-uniform
   unsigned rowoff[4];
@@ -195,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
   // iterator over (valid tap, channel chunk): state of the NEXT tile to load
   unsigned long long rem = tapmask;
   int cur_tap = __builtin_ctzll(rem);
-  int cur_chunk = it_first;
+  int cur_chunk = chunk_first;
   int ld_ky = 0, ld_kx = 0, ld_delta = 0, ld_koff = 0, ld_c0 = 0;
 
 #define FLM_TILE_PARAMS()                                                    \
@@ -206,11 +202,14 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
     ld_delta = (ld_ky * a.w + ld_kx) * a.cin;                                \
     ld_c0 = cur_chunk * BK;                                                  \
     ld_koff = cur_tap * a.cin + ld_c0;                                       \
-    if (++cur_chunk == a.cpt) {                                              \
-      cur_chunk = 0;                                                         \
-      rem &= rem - 1;                                                        \
-      cur_tap = rem ? __builtin_ctzll(rem) : 0;                              \
+    /* taps are the INNER loop: consecutive k-steps re-read the same pixels shifted by one tap, so the */ \
+    /* gathered rows are still in L1/L2 (chunk-inner order re-fetched them from beyond L2 nine times)    */ \
+    rem &= rem - 1;                                                          \
+    if (rem == 0) {                                                          \
+      rem = tapmask;                                                         \
+      if (++cur_chunk == chunk_end) cur_chunk = chunk_first;                 \
     }                                                                        \
+    cur_tap = __builtin_ctzll(rem);                                          \
   }
   // Out-of-bounds rows load a valid address (their own centre pixel) and are zeroed at the LDS write,
   // so loads issue with no branch around them.
@@ -443,7 +442,6 @@ int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
   a.mtiles = cdiv(a.M, BM);
   a.ntiles = d.coutpad / BN;
   a.cpt = d.cin / BK;
-  a.stagger = g_igemm_stagger;
   a.kw_magic = (65536 + d.kw - 1) / d.kw;
   // split-K for 1x1 layers whose tile grid cannot fill the chip (score5: 32 workgroups, 128 k-steps)
   a.ksplit = 1;

@@ -136,8 +136,7 @@ int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* 
  * returns its layer name and duration in ms; it returns 1 past the last record.
  * Process-global, not thread-safe: a measurement aid, off by default. */
 int flm_profile_enable(int max_records);
-/* Performance knobs (never change results): "igemm_stagger", "convt_stagger" = start delay, in units
- * of 64 cycles, of the second workgroup that lands on a CU (see csrc/flm_common.h). */
+/* Performance knobs (never change results); key "none" is always accepted, unknown keys fail. */
 int flm_set_tuning(const char* key, int value);
 /* Diagnostics for developers ("igemm_occupancy", arg = dynamic LDS bytes -> workgroups per CU). */
 int flm_debug_query(const char* key, int arg);

@@ -1,0 +1,92 @@
+"""GPU parity for the multi-face stream shape (BASELINE configs[4]):
+1080p frame + face boxes -> detect_marks box maths -> crop+resize -> batched FCN landmarks ->
+back-projection (reference prediction.py:16-96), and predict()/align() end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_ref, fcn_ref, warp_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import flm_amd  # noqa: F401
+    from flm_amd import prediction
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_fcn8_weights
+    params = synth_fcn8_weights(68, seed=2)
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+    model.load_weights(params)
+    return prediction, model, params
+
+
+def test_detect_marks_batch_1080p(setup):
+    prediction, model, params = setup
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    faces = [[100, 120, 300, 360], [900, 400, 1296, 700], [1700, 800, 1900, 1060]]
+    boxes = prediction.face_boxes(faces)
+    assert boxes == [warp_ref.square_box_ref(f) for f in faces]
+    fd = torch.from_numpy(frame).cuda()
+    crops = prediction.crop_faces_device(fd, boxes, 256, 256)
+    exp_crops = warp_ref.crop_resize_ref(frame, np.asarray(boxes), 256, 256)
+    d = np.abs(crops.cpu().numpy().astype(np.int32) - exp_crops.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    marks = prediction.detect_marks_batch(frame, model, faces, n_points=0)
+    assert marks.shape == (3, 68, 2) and marks.dtype == np.uint
+    # oracle on the SAME crops (the crop's rare 1-LSB rounding differences would otherwise move the input)
+    cg = crops.cpu().numpy()
+    x = np.stack([fcn_ref.get_image_array_ref(c) for c in cg])
+    pr = fcn_ref.fcn8_predict_ref(x, params).reshape(3, 264, 264, 68)
+    with np.errstate(all="ignore"):
+        lm = decode_ref.transfer_target_ref(pr, 0, 0).reshape(3, 68, 2)
+    for k, fb in enumerate(boxes):
+        m01 = (lm[k] / np.array([264.0, 264.0])).astype(np.float32)
+        exp = warp_ref.backproject_marks_ref(np.maximum(m01, 0), fb)
+        # astype(uint) truncates: a 1e-5 px difference can step an integer boundary
+        assert np.abs(marks[k].astype(np.int64) - exp.astype(np.int64)).max() <= 1
+    one = prediction.detect_marks(frame, model, faces[1])
+    assert one.shape == (68, 2)
+
+
+def test_predict_and_align_end_to_end(setup):
+    prediction, model, params = setup
+    rng = np.random.default_rng(6)
+    crops = rng.integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)
+    lm = prediction.predict(crops, model, n_points=0)               # numpy in -> numpy out
+    assert isinstance(lm, np.ndarray) and lm.shape == (3, 68, 2) and lm.dtype == np.float64
+    lm_in = prediction.predict(crops, model, n_points=0, to_input_space=True)
+    np.testing.assert_allclose(lm_in, lm * (256.0 / 264.0), rtol=1e-12)
+    aligned, m, lm2 = prediction.align(crops, model=model, out_size=(112, 112), n_points=0)
+    assert aligned.shape == (3, 112, 112, 3) and aligned.dtype == np.float32 and m.shape == (3, 2, 3)
+    assert np.array_equal(lm2, lm)
+    from flm_amd import alignment
+    tm = alignment.canonical_template(68, 112, 112)
+    m_ref = warp_ref.similarity_ref(lm * (256.0 / 264.0), tm)
+    np.testing.assert_allclose(m, m_ref, rtol=1e-5, atol=1e-5)
+    exp = warp_ref.warp_affine_ref(crops, m, 112, 112)              # same M: the warp itself is 1-ULP exact
+    assert np.abs(aligned - exp).max() <= 1e-3
+    # the aligned landmarks land on the template in the least-squares sense: residual no larger than
+    # before alignment
+    pts = lm * (256.0 / 264.0)
+    mapped = np.einsum("nij,nkj->nki", m[:, :, :2].astype(np.float64), pts) + m[:, None, :, 2]
+    assert np.linalg.norm(mapped - tm, axis=-1).mean() <= np.linalg.norm(pts * (112 / 256) - tm, axis=-1).mean() + 1e-6
+
+
+def test_keypts_predict_returns_class_map(setup, tmp_path):
+    prediction, model, params = setup
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    out = str(tmp_path / "seg.png")
+    cm = prediction.keypts_predict(model=model, inp=img, out_fname=out)
+    assert cm.shape == (264, 264) and cm.dtype == np.int64
+    ref_cm, pr = fcn_ref.prediction_ref(img, params, 68)
+    diff = cm != ref_cm
+    if diff.any():
+        srt = np.sort(pr.reshape(264, 264, 68), axis=-1)
+        assert (srt[..., -1] - srt[..., -2])[diff].max() < 2e-6
+    assert diff.mean() < 1e-3
+    import os
+    assert os.path.getsize(out) > 0
