@@ -32,6 +32,38 @@ FC6_GFLOP_PER_FACE = 6.5767      # fc6 7x7x256x4096 on 8x8, dense count (include
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 
 
+def fc6_issued_gflop(batch):
+    """MACs fc6 actually issues at this batch: position-major 128-row tiles skip the filter taps that see
+    only zero padding for the whole tile (csrc/flm_igemm_f32.hip); returned as 2*MAC in GFLOP."""
+    n, h, w, kh, pad, cin, cout = batch, 8, 8, 7, 3, 256, 4096
+    m_total = n * h * w
+    taps = 0
+    for t in range((m_total + 127) // 128):
+        lo, hi = t * 128, min(t * 128 + 128, m_total) - 1
+        valid = set()
+        for p in range(lo // n, hi // n + 1):
+            y, x = divmod(p, w)
+            for ky in range(kh):
+                if not 0 <= y + ky - pad < h:
+                    continue
+                for kx in range(kh):
+                    if 0 <= x + kx - pad < w:
+                        valid.add((ky, kx))
+        taps += len(valid)
+    return 2.0 * taps * 128 * cin * cout / 1e9
+
+
+def load_traffic(layer):
+    """HBM bytes per launch of a layer's kernel from the committed PMC summary (None when absent):
+    profiles/traffic_latest.json = {layer: FETCH_SIZE*2 + WRITE_SIZE in bytes}, see profiles/README.md."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(layer)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(n_faces, n_points, seed):
     """The oracle (kind "port": the build's CPU restatement of prediction.py's path) timed on the
     host cores: preprocess + FCN-8 forward + softmax + top-n decode for `n_faces` crops."""
@@ -161,8 +193,14 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "igemm_f32_kernel<MMAP=2,RELU> (fc6: 7x7x256->4096 on 8x8, M=64*B, K=12544)",
                          "achieved": fc6_tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fc6_tflops / PEAK_F32_TFLOPS, "traffic": None,
-                         "flop_per_launch": FC6_GFLOP_PER_FACE * 1e9 * B, "avg_launch_ms": fc6_ms},
+                         "frac": fc6_tflops / PEAK_F32_TFLOPS, "traffic": load_traffic("fc6"),
+                         "flop_per_launch": FC6_GFLOP_PER_FACE * 1e9 * B, "avg_launch_ms": fc6_ms,
+                         "issued_tflops": fc6_issued_gflop(B) / fc6_ms,
+                         "frac_issued": fc6_issued_gflop(B) / fc6_ms / PEAK_F32_TFLOPS,
+                         "note": "achieved counts the dense 2*MAC of SURVEY 8(d) (zero-padded taps included); the "
+                                 "kernel skips taps that only see padding, so fewer MFMAs are issued: "
+                                 "issued_tflops / frac_issued price the matrix pipe itself",
+                         "traffic_source": "profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"},
             "forward": {"gflop_per_face": GFLOP_PER_FACE, "ms": fwd_ms, "tflops": fwd_tflops,
                         "frac_of_f32_mfma_peak": fwd_tflops / PEAK_F32_TFLOPS,
                         "faces_per_s_forward_only": 1e3 * B / fwd_ms, "layer_ms": layer_avg},
