@@ -22,7 +22,7 @@ SOURCES = [
     "flm_api.hip",
     "flm_pack.hip",
     "flm_enc1.hip",
-    "flm_igemm_f32.hip",
+    "flm_igemm.hip",
     "flm_convt.hip",
     "flm_decode.hip",
     "flm_misc.hip",

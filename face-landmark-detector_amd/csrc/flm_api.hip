@@ -52,19 +52,20 @@ static size_t take(size_t& cur, size_t bytes) {
   return o;
 }
 
-Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int out_mode, int decode_mode, int n_points) {
+Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points) {
   Fcn8Ws W;
-  const ConvTGeom g = convt_geom(C);
+  const ConvTGeom g = convt_geom(C, dtype);
+  const size_t es = dtype == FLM_BF16 ? 2 : 4;  // activations f1..f5, fc6, fc7 are stored in the operand type
   size_t cur = 0;
   int hh = h, ww = w;
   for (int i = 0; i < 5; ++i) {
     hh >>= 1;
     ww >>= 1;
-    W.f[i] = take(cur, sizeof(float) * (size_t)n * hh * ww * kEncF[i]);
+    W.f[i] = take(cur, es * (size_t)n * hh * ww * kEncF[i]);
   }
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
-  W.fc6 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * kFc);
-  W.fc7 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * kFc);
+  W.fc6 = take(cur, es * (size_t)n * h5 * w5 * kFc);
+  W.fc7 = take(cur, es * (size_t)n * h5 * w5 * kFc);
   W.score5 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * g.Cp);
   W.fuse4 = take(cur, sizeof(float) * (size_t)n * h4 * w4 * g.Cp);
   W.seg = take(cur, sizeof(float) * (size_t)n * h3 * w3 * g.Cp);
@@ -83,8 +84,8 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int out_mode, int decode_mode,
 }
 
 static int check_fcn8_shape(int n, int h, int w, int C, int dtype) {
-  if (dtype != FLM_F32) {
-    set_error("fcn8: dtype %d is not built in this library (fp32 only)", dtype);
+  if (dtype != FLM_F32 && dtype != FLM_BF16) {
+    set_error("fcn8: unknown dtype %d (FLM_F32 = 0, FLM_BF16 = 1)", dtype);
     return FLM_ERR_UNSUPPORTED;
   }
   if (n <= 0 || h <= 0 || w <= 0 || (h % 32) || (w % 32)) {
@@ -102,13 +103,16 @@ static int check_fcn8_shape(int n, int h, int w, int C, int dtype) {
   return FLM_OK;
 }
 
-static int conv_layer(hipStream_t s, const char* blob, const ConvPack& c, const float* x, float* y, int n, int h,
-                      int w, int relu, int pool, int posmajor, float* splitk_ws = nullptr, size_t splitk_bytes = 0) {
+static int conv_layer(hipStream_t s, const char* blob, const ConvPack& c, const void* x, void* y, int n, int h,
+                      int w, int relu, int pool, int posmajor, int dtype, int out_f32 = 0,
+                      float* splitk_ws = nullptr, size_t splitk_bytes = 0) {
   IgemmDesc d;
+  d.bf16 = dtype == FLM_BF16;
+  d.out_f32 = out_f32;
   d.splitk_ws = splitk_ws;
   d.splitk_ws_bytes = splitk_bytes;
   d.x = x;
-  d.wt = reinterpret_cast<const float*>(blob + c.w);
+  d.wt = blob + c.w;
   d.scale = reinterpret_cast<const float*>(blob + c.scale);
   d.shift = reinterpret_cast<const float*>(blob + c.shift);
   d.y = y;
@@ -116,7 +120,7 @@ static int conv_layer(hipStream_t s, const char* blob, const ConvPack& c, const 
   d.cout = c.cout; d.coutpad = c.coutpad; d.ldc = c.cout;
   d.kh = c.kh; d.kw = c.kw; d.pad = c.pad;
   d.relu = relu; d.pool = pool; d.posmajor = posmajor;
-  return launch_igemm_f32(s, d);
+  return launch_igemm(s, d);
 }
 
 }  // namespace flm
@@ -187,8 +191,8 @@ int flm_profile_disable(void) {
 const char* flm_last_error(void) { return g_err; }
 
 size_t flm_fcn8_packed_bytes(int n_classes, int dtype) {
-  if (dtype != FLM_F32 || n_classes < 1 || n_classes > kMaxClasses) return 0;
-  return fcn8_pack_layout(n_classes).total;
+  if ((dtype != FLM_F32 && dtype != FLM_BF16) || n_classes < 1 || n_classes > kMaxClasses) return 0;
+  return fcn8_pack_layout(n_classes, dtype).total;
 }
 
 int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
@@ -197,15 +201,15 @@ int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, 
     set_error("flm_fcn8_pack: null argument");
     return FLM_ERR_ARG;
   }
-  if (dtype != FLM_F32) {
-    set_error("flm_fcn8_pack: dtype %d not built (fp32 only)", dtype);
+  if (dtype != FLM_F32 && dtype != FLM_BF16) {
+    set_error("flm_fcn8_pack: unknown dtype %d", dtype);
     return FLM_ERR_UNSUPPORTED;
   }
   if (n_classes < 1 || n_classes > kMaxClasses) {
     set_error("flm_fcn8_pack: n_classes must be in [1,%d]", kMaxClasses);
     return FLM_ERR_SHAPE;
   }
-  const Fcn8Pack L = fcn8_pack_layout(n_classes);
+  const Fcn8Pack L = fcn8_pack_layout(n_classes, dtype);
   if (packed_bytes < L.total) {
     set_error("flm_fcn8_pack: packed buffer too small (%zu < %zu)", packed_bytes, L.total);
     return FLM_ERR_WORKSPACE;
@@ -216,13 +220,13 @@ int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, 
 size_t flm_fcn8_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
                                 int n_points) {
   if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
-  return fcn8_ws_layout(n, h, w, n_classes, out_mode, decode_mode, n_points).total;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points).total;
 }
 
 int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype, int out_mode,
                                   int decode_mode, int n_points) {
   if (!name || check_fcn8_shape(n, h, w, n_classes, dtype)) return -1;
-  const Fcn8Ws W = fcn8_ws_layout(n, h, w, n_classes, out_mode, decode_mode, n_points);
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points);
   if (name[0] == 'f' && name[1] >= '1' && name[1] <= '5' && name[2] == 0) return (int64_t)W.f[name[1] - '1'];
   if (!strcmp(name, "fc6")) return (int64_t)W.fc6;
   if (!strcmp(name, "fc7")) return (int64_t)W.fc7;
@@ -246,19 +250,20 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
     set_error("flm_fcn8_forward: unknown output mode %d", out_mode);
     return FLM_ERR_ARG;
   }
-  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, out_mode, decode_mode, n_points);
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points);
   if (workspace_bytes < W.total) {
     set_error("flm_fcn8_forward: workspace too small (%zu < %zu)", workspace_bytes, W.total);
     return FLM_ERR_WORKSPACE;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const Fcn8Pack L = fcn8_pack_layout(C);
+  const Fcn8Pack L = fcn8_pack_layout(C, dtype);
+  const int bf = dtype == FLM_BF16;
   const char* blob = static_cast<const char*>(packed_dev);
   char* ws = static_cast<char*>(workspace_dev);
-  float* f[5];
-  for (int i = 0; i < 5; ++i) f[i] = reinterpret_cast<float*>(ws + W.f[i]);
-  float* fc6 = reinterpret_cast<float*>(ws + W.fc6);
-  float* fc7 = reinterpret_cast<float*>(ws + W.fc7);
+  void* f[5];
+  for (int i = 0; i < 5; ++i) f[i] = ws + W.f[i];
+  void* fc6 = ws + W.fc6;
+  void* fc7 = ws + W.fc7;
   float* score5 = reinterpret_cast<float*>(ws + W.score5);
   float* fuse4 = reinterpret_cast<float*>(ws + W.fuse4);
   float* seg = reinterpret_cast<float*>(ws + W.seg);
@@ -267,13 +272,13 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
   { ProfScope ps(s, "enc1");
   rc = launch_enc1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
                    reinterpret_cast<const float*>(blob + L.enc1_scale),
-                   reinterpret_cast<const float*>(blob + L.enc1_shift), f[0]); }
+                   reinterpret_cast<const float*>(blob + L.enc1_shift), f[0], bf); }
   if (rc) return rc;
   int hh = h / 2, ww = w / 2;
   for (int i = 0; i < 4; ++i) {
     static const char* const enc_names[4] = {"enc2", "enc3", "enc4", "enc5"};
     { ProfScope ps(s, enc_names[i]);
-    rc = conv_layer(s, blob, L.enc[i], f[i], f[i + 1], n, hh, ww, /*relu*/ 1, /*pool*/ 1, 0); }
+    rc = conv_layer(s, blob, L.enc[i], f[i], f[i + 1], n, hh, ww, /*relu*/ 1, /*pool*/ 1, 0, dtype); }
     if (rc) return rc;
     hh /= 2;
     ww /= 2;
@@ -281,40 +286,40 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
   // head (fcn.py:98-103); Dropout is the identity at inference
   { ProfScope ps(s, "fc6");
-  rc = conv_layer(s, blob, L.fc6, f[4], fc6, n, h5, w5, 1, 0, /*posmajor*/ 1); }
+  rc = conv_layer(s, blob, L.fc6, f[4], fc6, n, h5, w5, 1, 0, /*posmajor*/ 1, dtype); }
   if (rc) return rc;
   { ProfScope ps(s, "fc7");
-  rc = conv_layer(s, blob, L.fc7, fc6, fc7, n, h5, w5, 1, 0, 0); }
+  rc = conv_layer(s, blob, L.fc7, fc6, fc7, n, h5, w5, 1, 0, 0, dtype); }
   if (rc) return rc;
   { ProfScope ps(s, "score5");
-  rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0, reinterpret_cast<float*>(ws + W.splitk),
-                  W.splitk_bytes); }
+  rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0, dtype, /*out_f32*/ 1,
+                  reinterpret_cast<float*>(ws + W.splitk), W.splitk_bytes); }
   if (rc) return rc;
   // skip branches: score4 on f4 -> fuse4 buffer, score3 on f3 -> seg buffer, then the transposed
   // convs add themselves onto those (crop keeps the top-left window, fcn.py:76-84)
   { ProfScope ps(s, "score4");
-  rc = conv_layer(s, blob, L.score4, f[3], fuse4, n, h4, w4, 0, 0, 0); }
+  rc = conv_layer(s, blob, L.score4, f[3], fuse4, n, h4, w4, 0, 0, 0, dtype, 1); }
   if (rc) return rc;
   { ProfScope ps(s, "score3");
-  rc = conv_layer(s, blob, L.score3, f[2], seg, n, h3, w3, 0, 0, 0); }
+  rc = conv_layer(s, blob, L.score3, f[2], seg, n, h3, w3, 0, 0, 0, dtype, 1); }
   if (rc) return rc;
   ConvTDesc t;
   t.g = L.g;
   t.n = n;
   // up5 (fcn.py:104) + crop + Add (fcn.py:110-112), in place on fuse4
-  t.x = score5; t.wf = reinterpret_cast<const float*>(blob + L.up5); t.skip = fuse4; t.y = fuse4;
+  t.x = score5; t.wf = blob + L.up5; t.skip = fuse4; t.y = fuse4;
   t.hi = h5; t.wi = w5; t.ho = h4; t.wo = w4; t.s = 2; t.ldy = L.g.Cp; t.epilogue = 0;
   { ProfScope ps(s, "up5");
   rc = launch_convt(s, t); }
   if (rc) return rc;
   // up4 (fcn.py:114) + crop + Add (fcn.py:118-119), in place on seg ("seg_feats")
-  t.x = fuse4; t.wf = reinterpret_cast<const float*>(blob + L.up4); t.skip = seg; t.y = seg;
+  t.x = fuse4; t.wf = blob + L.up4; t.skip = seg; t.y = seg;
   t.hi = h4; t.wi = w4; t.ho = h3; t.wo = w3;
   { ProfScope ps(s, "up4");
   rc = launch_convt(s, t); }
   if (rc) return rc;
   // up3 (fcn.py:121) + softmax (networks/utils.py:30) / argmax (prediction.py:209)
-  t.x = seg; t.wf = reinterpret_cast<const float*>(blob + L.up3); t.skip = nullptr;
+  t.x = seg; t.wf = blob + L.up3; t.skip = nullptr;
   t.hi = h3; t.wi = w3; t.ho = W.oh; t.wo = W.ow; t.s = 8; t.ldy = C;
   if (out_mode == FLM_OUT_LOGITS || out_mode == FLM_OUT_PROBS) {
     t.y = out_dev;
@@ -345,26 +350,26 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
                        decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
 }
 
-int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const float* x_dev,
-                       float* y_dev, int n, int h, int w, int C, int dtype) {
+int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const void* x_dev,
+                       void* y_dev, int n, int h, int w, int C, int dtype) {
   if (!packed_dev || !layer || !x_dev || !y_dev || n <= 0 || h <= 0 || w <= 0) {
     set_error("flm_fcn8_run_layer: bad argument");
     return FLM_ERR_ARG;
   }
-  if (dtype != FLM_F32 || C < 1 || C > kMaxClasses) {
+  if ((dtype != FLM_F32 && dtype != FLM_BF16) || C < 1 || C > kMaxClasses) {
     set_error("flm_fcn8_run_layer: unsupported dtype/n_classes");
     return FLM_ERR_UNSUPPORTED;
   }
-  const Fcn8Pack L = fcn8_pack_layout(C);
+  const Fcn8Pack L = fcn8_pack_layout(C, dtype);
   const char* blob = static_cast<const char*>(packed_dev);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!strncmp(layer, "enc", 3) && layer[3] >= '2' && layer[3] <= '5' && layer[4] == 0)
-    return conv_layer(s, blob, L.enc[layer[3] - '2'], x_dev, y_dev, n, h, w, 1, 1, 0);
-  if (!strcmp(layer, "fc6")) return conv_layer(s, blob, L.fc6, x_dev, y_dev, n, h, w, 1, 0, 1);
-  if (!strcmp(layer, "fc7")) return conv_layer(s, blob, L.fc7, x_dev, y_dev, n, h, w, 1, 0, 0);
-  if (!strcmp(layer, "score5")) return conv_layer(s, blob, L.score5, x_dev, y_dev, n, h, w, 0, 0, 0);
-  if (!strcmp(layer, "score4")) return conv_layer(s, blob, L.score4, x_dev, y_dev, n, h, w, 0, 0, 0);
-  if (!strcmp(layer, "score3")) return conv_layer(s, blob, L.score3, x_dev, y_dev, n, h, w, 0, 0, 0);
+    return conv_layer(s, blob, L.enc[layer[3] - '2'], x_dev, y_dev, n, h, w, 1, 1, 0, dtype);
+  if (!strcmp(layer, "fc6")) return conv_layer(s, blob, L.fc6, x_dev, y_dev, n, h, w, 1, 0, 1, dtype);
+  if (!strcmp(layer, "fc7")) return conv_layer(s, blob, L.fc7, x_dev, y_dev, n, h, w, 1, 0, 0, dtype);
+  if (!strcmp(layer, "score5")) return conv_layer(s, blob, L.score5, x_dev, y_dev, n, h, w, 0, 0, 0, dtype, 1);
+  if (!strcmp(layer, "score4")) return conv_layer(s, blob, L.score4, x_dev, y_dev, n, h, w, 0, 0, 0, dtype, 1);
+  if (!strcmp(layer, "score3")) return conv_layer(s, blob, L.score3, x_dev, y_dev, n, h, w, 0, 0, 0, dtype, 1);
   set_error("flm_fcn8_run_layer: unknown layer '%s'", layer);
   return FLM_ERR_ARG;
 }

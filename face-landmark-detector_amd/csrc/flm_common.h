@@ -37,15 +37,16 @@ constexpr int kMaxClasses = 96;
 // Geometry of the transposed-conv kernels for a class count C.
 struct ConvTGeom {
   int C;   // classes
-  int Cp;  // channel stride of the score / fuse buffers (multiple of 4)
+  int Cp;  // channel stride of the (fp32) score / fuse buffers: multiple of 4 (fp32) or 8 (bf16)
   int MT;  // 16-row class tiles
-  int G;   // 16-deep k groups over K = 4 taps * Cp
+  int G;   // k groups over K = 4 taps * Cp: 16 deep (fp32, 16x16x4 MFMA x4) or 32 deep (bf16, 16x16x32)
+  int bf16;
 };
-ConvTGeom convt_geom(int C);
+ConvTGeom convt_geom(int C, int dtype);
 
 // One implicit-GEMM conv layer inside the packed blob (offsets in bytes).
 struct ConvPack {
-  size_t w;      // float [coutpad][kh*kw*cin], k = (ky*kw+kx)*cin + c
+  size_t w;      // fp32 or bf16 [coutpad][kh*kw*cin], k = (ky*kw+kx)*cin + c
   size_t scale;  // float [coutpad]
   size_t shift;  // float [coutpad]
   int cin, cout, coutpad, kh, kw, pad;
@@ -56,11 +57,12 @@ struct Fcn8Pack {
   size_t enc1_scale, enc1_shift;
   ConvPack enc[4];  // enc2..enc5
   ConvPack fc6, fc7, score5, score4, score3;
-  size_t up5, up4, up3;  // float [s*s phases][G][MT][64 lanes][4]
+  size_t up5, up4, up3;  // [s*s phases][G][MT][64 lanes][16 bytes: 4 fp32 or 8 bf16]
   ConvTGeom g;
+  int dtype;
   size_t total;
 };
-Fcn8Pack fcn8_pack_layout(int C);
+Fcn8Pack fcn8_pack_layout(int C, int dtype);
 
 // Workspace of the forward (offsets in bytes).
 struct Fcn8Ws {
@@ -73,20 +75,22 @@ struct Fcn8Ws {
   size_t total;
   int oh, ow;
 };
-Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int out_mode, int decode_mode, int n_points);
+Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points);
 
 // ---- kernel launchers (each returns FLM_OK or an error) --------------------------------------
 int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8Pack& L, char* blob);
 
 int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
-                const float* scale, const float* shift, float* f1);
+                const float* scale, const float* shift, void* f1, int out_bf16);
 
 struct IgemmDesc {
-  const float* x;      // [n,h,w,cin]
-  const float* wt;     // [coutpad][K]
+  const void* x;       // [n,h,w,cin] fp32, or bf16 when `bf16`
+  const void* wt;      // [coutpad][K], same type as x
   const float* scale;  // [coutpad]
   const float* shift;  // [coutpad]
-  float* y;            // [n,ho,wo,ldc]  (ho,wo = h,w or h/2,w/2 when pooled)
+  void* y;             // [n,ho,wo,ldc]  (ho,wo = h,w or h/2,w/2 when pooled); bf16 unless out_f32
+  int bf16;            // operands are bf16 (v_mfma_f32_32x32x16_bf16), accumulate fp32
+  int out_f32;         // bf16 path: store fp32 (score convs feeding the fp32 decoder buffers)
   int n, h, w, cin;
   int cout;     // columns stored
   int coutpad;  // rows of wt (multiple of 128)
@@ -96,12 +100,12 @@ struct IgemmDesc {
   float* splitk_ws;        // optional scratch for split-K partial sums (null: never split)
   size_t splitk_ws_bytes;
 };
-int launch_igemm_f32(hipStream_t s, const IgemmDesc& d);
+int launch_igemm(hipStream_t s, const IgemmDesc& d);
 int igemm_occupancy(size_t lds_bytes);
 
 struct ConvTDesc {
   const float* x;     // [n,hi,wi,Cp]
-  const float* wf;    // fragment-packed weights
+  const void* wf;     // fragment-packed weights (fp32 or bf16 per g.bf16)
   const float* skip;  // [n,ho,wo,Cp] added to the result, or null
   void* y;            // logits/probs float [n,ho,wo,ldy] or int32 class map [n,ho,wo]
   int n, hi, wi;      // input grid

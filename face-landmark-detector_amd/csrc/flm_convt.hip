@@ -26,10 +26,11 @@
 namespace flm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvTArgs {
   const float* x;
-  const float* wf;
+  const void* wf;
   const float* skip;
   void* y;
   int n, hi, wi, ho, wo, s, ldy, epilogue;
@@ -39,8 +40,8 @@ struct ConvTArgs {
 
 constexpr int GCH = 6;  // k groups per LDS chunk
 
-template <int MT, int G>
-__global__ __launch_bounds__(256, (MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
+template <int MT, int G, bool BF>
+__global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
   constexpr int NCH = (G + GCH - 1) / GCH;
   constexpr int CHUNK_F4 = GCH * MT * 64;             // float4 per full chunk
   constexpr int NLD = (CHUNK_F4 + 255) / 256;         // staging loads per thread
@@ -59,17 +60,34 @@ __global__ __launch_bounds__(256, (MT >= 5 && G >= 20) ? 1 : 2) void convt_kerne
   const int wi1 = a.wi + 1, hi1 = a.hi + 1;
   const int j0 = pp % wi1, i0 = (pp / wi1) % hi1, img = pp / (wi1 * hi1);
 
-  // ---- X fragments: xf[g] = x[tap(k4)][c(k4)..+3], k4 = 16g + 4q --------------------------------
+  // ---- X fragments ------------------------------------------------------------------------------------
+  //   fp32: xf[g] = x[tap(k4)][c(k4)..+3],  k4 = 16g + 4q   (4 floats)
+  //   bf16: xf[g] = bf16(x[tap(k8)][c(k8)..+7]), k8 = 32g + 8q (8 floats converted, 16 bytes)
   float4 xf[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const int k4 = 16 * g + 4 * q;
-    const int tap = k4 / a.Cp, c = k4 % a.Cp;
+    constexpr int EPL = BF ? 8 : 4;
+    const int k0 = 4 * EPL * g + EPL * q;
+    const int tap = k0 / a.Cp, c = k0 % a.Cp;
     const int ii = i0 - (tap >> 1), jj = j0 - (tap & 1);
     const bool ok = pvalid && tap < 4 && (unsigned)ii < (unsigned)a.hi && (unsigned)jj < (unsigned)a.wi;
     const size_t off = ok ? (((size_t)img * a.hi + ii) * a.wi + jj) * a.Cp + c : 0;
-    const float4 v = *reinterpret_cast<const float4*>(a.x + off);
-    xf[g] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (component-wise selects: a float4 struct select goes through scratch memory)
+    const float km = ok ? 1.f : 0.f;
+    if constexpr (BF) {
+      const float4 v0 = *reinterpret_cast<const float4*>(a.x + off);
+      const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
+      bf16x8 t;
+      t[0] = (__bf16)(ok ? v0.x : 0.f); t[1] = (__bf16)(ok ? v0.y : 0.f);
+      t[2] = (__bf16)(ok ? v0.z : 0.f); t[3] = (__bf16)(ok ? v0.w : 0.f);
+      t[4] = (__bf16)(ok ? v1.x : 0.f); t[5] = (__bf16)(ok ? v1.y : 0.f);
+      t[6] = (__bf16)(ok ? v1.z : 0.f); t[7] = (__bf16)(ok ? v1.w : 0.f);
+      xf[g] = __builtin_bit_cast(float4, t);
+    } else {
+      const float4 v = *reinterpret_cast<const float4*>(a.x + off);
+      xf[g] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    (void)km;
   }
 
   // ---- weight stream: (b0, chunk) sequence for this phase row ------------------------------------
@@ -221,14 +239,21 @@ __global__ __launch_bounds__(256, (MT >= 5 && G >= 20) ? 1 : 2) void convt_kerne
           float4 af[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) af[m] = wl[(gl * MT + m) * 64 + lane];
+          if constexpr (BF) {
+            const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[g]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[g].x, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m)
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, acc[m], 0, 0, 0);
+          } else {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[g].y, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[g].x, acc[m], 0, 0, 0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[g].z, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[g].y, acc[m], 0, 0, 0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[g].w, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[g].z, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[g].w, acc[m], 0, 0, 0);
+          }
         }
       }
       if (more) FLM_STASH((seq + 1) & 1)
@@ -254,17 +279,17 @@ __global__ __launch_bounds__(256, (MT >= 5 && G >= 20) ? 1 : 2) void convt_kerne
 #undef FLM_LD1
 #undef FLM_ST1
 
-template <int MT, int G>
+template <int MT, int G, bool BF>
 static int launch_t(hipStream_t st, const ConvTArgs& a) {
   constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64;
   static bool attr_done = false;
   if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G>),
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   dim3 grid(cdiv(a.P, 64), a.s);
-  convt_kernel<MT, G><<<grid, 256, lds, st>>>(a);
+  convt_kernel<MT, G, BF><<<grid, 256, lds, st>>>(a);
   FLM_LAUNCH_CHECK("convt_kernel");
   return FLM_OK;
 }
@@ -284,14 +309,26 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     set_error("convt: raw epilogue needs a channel stride that is a multiple of 4");
     return FLM_ERR_SHAPE;
   }
-  if (d.g.C == 68 && d.g.G == 17) return launch_t<5, 17>(st, a);
-  switch (d.g.MT) {
-    case 1: return launch_t<1, 4>(st, a);
-    case 2: return launch_t<2, 8>(st, a);
-    case 3: return launch_t<3, 12>(st, a);
-    case 4: return launch_t<4, 16>(st, a);
-    case 5: return launch_t<5, 20>(st, a);
-    case 6: return launch_t<6, 24>(st, a);
+  if (d.g.bf16) {
+    if (d.g.C == 68 && d.g.G == 9) return launch_t<5, 9, true>(st, a);
+    switch (d.g.MT) {
+      case 1: return launch_t<1, 2, true>(st, a);
+      case 2: return launch_t<2, 4, true>(st, a);
+      case 3: return launch_t<3, 6, true>(st, a);
+      case 4: return launch_t<4, 8, true>(st, a);
+      case 5: return launch_t<5, 10, true>(st, a);
+      case 6: return launch_t<6, 12, true>(st, a);
+    }
+  } else {
+    if (d.g.C == 68 && d.g.G == 17) return launch_t<5, 17, false>(st, a);
+    switch (d.g.MT) {
+      case 1: return launch_t<1, 4, false>(st, a);
+      case 2: return launch_t<2, 8, false>(st, a);
+      case 3: return launch_t<3, 12, false>(st, a);
+      case 4: return launch_t<4, 16, false>(st, a);
+      case 5: return launch_t<5, 20, false>(st, a);
+      case 6: return launch_t<6, 24, false>(st, a);
+    }
   }
   set_error("convt: n_classes %d not supported (max %d)", d.g.C, kMaxClasses);
   return FLM_ERR_SHAPE;

@@ -25,10 +25,10 @@ __device__ __forceinline__ int koff_of(int k) {  // halo offset of patch element
   return (k < 27) ? (k / 9) * HALO_STRIDE + (k % 9) : -1;
 }
 
-template <bool U8>
+template <bool U8, bool OBF>
 __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin, const float* __restrict__ w1p,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   float* __restrict__ f1, int n, int h, int w) {
+                                                   void* __restrict__ f1, int n, int h, int w) {
   __shared__ __attribute__((aligned(16))) float halo[HALO_F];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hp = h >> 1, wp = w >> 1;
@@ -110,23 +110,29 @@ __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin,
 #pragma unroll
         for (int e = 0; e < 4; ++e) v = fmaxf(v, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
         const int xp = xp0 + 8 * wave + 2 * g + lh;
-        if (xp < wp) f1[(((size_t)img * hp + yp) * wp + xp) * 64 + 32 * j + lr] = v;
+        if (xp < wp) {
+          const size_t o = (((size_t)img * hp + yp) * wp + xp) * 64 + 32 * j + lr;
+          if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
+          else reinterpret_cast<float*>(f1)[o] = v;
+        }
       }
   }
 }
 
 int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
-                const float* scale, const float* shift, float* f1) {
+                const float* scale, const float* shift, void* f1, int out_bf16) {
   if ((h & 1) || (w & 1)) {
     set_error("enc1: h,w must be even");
     return FLM_ERR_SHAPE;
   }
   const int blocks = n * (h >> 1);
-  if (in_format == FLM_IN_U8_BGR)
-    enc1_kernel<true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-  else if (in_format == FLM_IN_F32_RGB)
-    enc1_kernel<false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-  else {
+  if (in_format == FLM_IN_U8_BGR) {
+    if (out_bf16) enc1_kernel<true, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+    else enc1_kernel<true, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  } else if (in_format == FLM_IN_F32_RGB) {
+    if (out_bf16) enc1_kernel<false, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+    else enc1_kernel<false, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  } else {
     set_error("enc1: unknown input format %d", in_format);
     return FLM_ERR_ARG;
   }

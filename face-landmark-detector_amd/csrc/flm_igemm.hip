@@ -1,4 +1,9 @@
-// Implicit-GEMM convolution, exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM convolution on the matrix cores, one kernel body for two arithmetic types:
+//   fp32  v_mfma_f32_32x32x2_f32   (exact fp32: bit-for-bit an fmaf chain)         -- the parity path
+//   bf16  v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate, 16x the rate)  -- BASELINE configs[2]
+// Both use 128-byte operand rows (32 floats / 64 bf16) and 16-byte fragments per lane, so the tile
+// geometry, the LDS swizzle, the staging code and the fragment addressing are shared; only the MFMA
+// slot and the output conversion differ.
 //
 // Covers every Conv2D of the reference's fcn_8 + vanilla_encoder except enc1
 // (networks/fcn.py:33-48 enc2..5 with ZeroPadding2D(1)+BN+ReLU+MaxPool fused; :98 fc6 7x7 'same';
@@ -29,27 +34,29 @@
 namespace flm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct IgemmArgs {
-  const float* x;
-  const float* wt;
+  const void* x;       // fp32 or bf16 [n,h,w,cin]
+  const void* wt;      // same type, [coutpad][K]
   const float* scale;
   const float* shift;
-  float* y;
+  void* y;             // operand type, or fp32 when out_f32
+  int out_f32;
   int n, h, w, cin;
   int cout, ldc;
   int kh, kw, pad;
   int M;        // n*h*w
   int K;        // kh*kw*cin
   int mtiles, ntiles;
-  int cpt;      // 32-channel chunks per tap = cin/32
+  int cpt;      // 128-byte channel chunks per tap = cin/32 (fp32) or cin/64 (bf16)
   int kw_magic; // ceil(65536 / kw): tap / kw == (tap * kw_magic) >> 16 for tap < 64
   int ksplit;   // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to `part`
   float* part;  // [ksplit][M][ldc]
 };
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int TILE_F = BM * BK;  // floats per operand tile
+constexpr int BM = 128, BN = 128, BK = 32;   // BK in 4-byte units: a k-step is 128 bytes of every row
+constexpr int TILE_F = BM * BK;             // 4-byte units per operand tile (16 KiB)
 
 // Taps of a kh x kw 'same' filter that touch at least one in-bounds pixel for m-tile t in
 // position-major order (positions t*BM/n .. of an h x w map): bit ky*kw+kx.
@@ -70,8 +77,36 @@ __device__ __forceinline__ unsigned long long posmajor_tapmask(int t, int M, int
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-template <int MMAP, bool RELU>
-__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// One of the 16 MFMA slots of a k-step.
+//   fp32: component IDX of the four 16-byte fragments feeds all four 32x32 tiles (k = 8t+4h+IDX);
+//   bf16: the whole fragments (8 bf16 = k 8h..8h+7 of a 16-deep step) feed tile IDX = 2*i + j.
+template <bool BF, int IDX>
+__device__ __forceinline__ void mfma_slot(const float4& a0, const float4& a1, const float4& b0, const float4& b1,
+                                          f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
+  if constexpr (BF) {
+    const float4& av = (IDX >> 1) ? a1 : a0;
+    const float4& bv = (IDX & 1) ? b1 : b0;
+    const bf16x8 af = __builtin_bit_cast(bf16x8, av), bfr = __builtin_bit_cast(bf16x8, bv);
+    if constexpr (IDX == 0) c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, c00, 0, 0, 0);
+    if constexpr (IDX == 1) c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, c01, 0, 0, 0);
+    if constexpr (IDX == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, c10, 0, 0, 0);
+    if constexpr (IDX == 3) c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, c11, 0, 0, 0);
+  } else {
+    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, IDX), f4c(b0, IDX), c00, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, IDX), f4c(b1, IDX), c01, 0, 0, 0);
+    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, IDX), f4c(b0, IDX), c10, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, IDX), f4c(b1, IDX), c11, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
+template <bool BF, int MMAP, bool RELU>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
+  constexpr int ES = BF ? 2 : 4;    // operand element size
+  constexpr int EPC = 16 / ES;      // elements per 16-byte chunk
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);  // [2][TILE_F]
   float* Bs = As + 2 * TILE_F;                     // [2][TILE_F]
@@ -166,13 +201,16 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
   }
   const int nit = __builtin_popcountll(tapmask) * (chunk_end - chunk_first);
 
-  // per-row element offset of the centre pixel; per-tap displacement is wave-uniform
+  // per-row BYTE offset of the centre pixel; per-tap displacement is wave-uniform
   unsigned rowoff[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(((pn[j] * a.h + py[j]) * a.w + px[j]) * a.cin) + 4 * c8;
-  const float* wrow[4];
+  for (int j = 0; j < 4; ++j)
+    rowoff[j] = ((unsigned)(((pn[j] * a.h + py[j]) * a.w + px[j]) * a.cin) + EPC * c8) * ES;
+  const char* wrow[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wrow[j] = a.wt + (size_t)(n0 + r0 + 32 * j) * a.K + 4 * c8;
+  for (int j = 0; j < 4; ++j)
+    wrow[j] = reinterpret_cast<const char*>(a.wt) + ((size_t)(n0 + r0 + 32 * j) * a.K + EPC * c8) * ES;
+  const char* xbase = reinterpret_cast<const char*>(a.x);
 
   // ---- software pipeline ---------------------------------------------------------------------------
   // Step t computes tile t from LDS[t&1]; in the SAME step, spread between the 64 MFMAs, it issues the
@@ -199,9 +237,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
     const int ty = (cur_tap * a.kw_magic) >> 16;                             \
     ld_ky = ty - a.pad;                                                      \
     ld_kx = cur_tap - ty * a.kw - a.pad;                                     \
-    ld_delta = (ld_ky * a.w + ld_kx) * a.cin;                                \
-    ld_c0 = cur_chunk * BK;                                                  \
-    ld_koff = cur_tap * a.cin + ld_c0;                                       \
+    ld_delta = (ld_ky * a.w + ld_kx) * a.cin * ES;                           \
+    ld_c0 = cur_chunk * 128;                                                 \
+    ld_koff = cur_tap * a.cin * ES + ld_c0;                                  \
     /* taps are the INNER loop: consecutive k-steps re-read the same pixels shifted by one tap, so the */ \
     /* gathered rows are still in L1/L2 (chunk-inner order re-fetched them from beyond L2 nine times)    */ \
     rem &= rem - 1;                                                          \
@@ -218,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
     const int iy = py[J] + ld_ky, ix = px[J] + ld_kx;                                          \
     OK = pv[J] && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;               \
     const unsigned off = rowoff[J] + (OK ? (unsigned)ld_delta : 0u) + (unsigned)ld_c0;         \
-    RA = *reinterpret_cast<const float4*>(a.x + off);                                          \
+    RA = *reinterpret_cast<const float4*>(xbase + off);                                        \
   }
 #define FLM_LOAD_B(J, RB) RB = *reinterpret_cast<const float4*>(wrow[J] + ld_koff);
 #define FLM_STORE_A(J, RA, OK) \
@@ -244,11 +282,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
   AF1 = *reinterpret_cast<const float4*>(Ab + fa1 + FC);                         \
   BF0 = *reinterpret_cast<const float4*>(Bb + fb0 + FC);                         \
   BF1 = *reinterpret_cast<const float4*>(Bb + fb1 + FC);
-#define FLM_MFMA4(AF0, AF1, BF0, BF1, E)                                         \
-  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF0.E, BF0.E, acc00, 0, 0, 0);    \
-  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF0.E, BF1.E, acc01, 0, 0, 0);    \
-  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF1.E, BF0.E, acc10, 0, 0, 0);    \
-  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(AF1.E, BF1.E, acc11, 0, 0, 0);    \
+#define FLM_SLOT_x 0
+#define FLM_SLOT_y 1
+#define FLM_SLOT_z 2
+#define FLM_SLOT_w 3
+#define FLM_MFMA4(AF0, AF1, BF0, BF1, E)                                                     \
+  mfma_slot<BF, FLM_SLOT_##E>(AF0, AF1, BF0, BF1, acc00, acc01, acc10, acc11);               \
   __builtin_amdgcn_sched_barrier(0);
 
   // One step.  W* = register set written to LDS now (tile it+1), L* = set receiving the loads of tile it+2.
@@ -322,6 +361,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
 #undef FLM_STORE_B
 #undef FLM_READ_FRAGS
 #undef FLM_MFMA4
+#undef FLM_SLOT_x
+#undef FLM_SLOT_y
+#undef FLM_SLOT_z
+#undef FLM_SLOT_w
 #undef FLM_STEP
 
   // ---- epilogue: y = acc*scale + shift, ReLU, 2x2 max-pool (MMAP 1), store ---------------------
@@ -347,7 +390,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
             v = fmaxf(v, u);
           }
           const int m = mbase + 8 * g + 4 * lh;  // first row of the quad
-          if (cok && m < a.M) a.y[(size_t)(m >> 2) * a.ldc + col] = v;
+          if (cok && m < a.M) {
+            const size_t o = (size_t)(m >> 2) * a.ldc + col;
+            if (BF && !a.out_f32) reinterpret_cast<unsigned short*>(a.y)[o] = f2bf(v);
+            else reinterpret_cast<float*>(a.y)[o] = v;
+          }
         }
       } else {
 #pragma unroll
@@ -367,7 +414,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
             } else {
               orow = (size_t)m;
             }
-            a.y[orow * a.ldc + col] = u;
+            const size_t o = orow * a.ldc + col;
+            if (BF && !a.out_f32) reinterpret_cast<unsigned short*>(a.y)[o] = f2bf(u);
+            else reinterpret_cast<float*>(a.y)[o] = u;
           }
         }
       }
@@ -376,18 +425,18 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(IgemmArgs a) {
   }  // pass
 }
 
-template <int MMAP, bool RELU>
+template <bool BF, int MMAP, bool RELU>
 static int launch_t(hipStream_t s, const IgemmArgs& a) {
   const size_t lds = sizeof(float) * 4 * TILE_F + 64;
   static bool attr_done = false;
   if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<MMAP, RELU>),
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BF, MMAP, RELU>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
-  igemm_f32_kernel<MMAP, RELU><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
-  FLM_LAUNCH_CHECK("igemm_f32_kernel");
+  igemm_kernel<BF, MMAP, RELU><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
+  FLM_LAUNCH_CHECK("igemm_kernel");
   return FLM_OK;
 }
 
@@ -409,45 +458,57 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
 
 int igemm_occupancy(size_t lds_bytes) {
   int nb = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&igemm_f32_kernel<0, true>), 256,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&igemm_kernel<false, 0, true>), 256,
                                                    lds_bytes) != hipSuccess)
     return -1;
   return nb;
 }
 
-int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
-  if (d.cin % 32 != 0 || d.coutpad % BN != 0 || d.cout > d.coutpad || d.kh * d.kw > 64) {
-    set_error("igemm_f32: unsupported shape cin=%d coutpad=%d cout=%d k=%dx%d", d.cin, d.coutpad, d.cout, d.kh, d.kw);
+template <bool BF>
+static int dispatch(hipStream_t s, const IgemmDesc& d, const IgemmArgs& a) {
+  if (d.pool) return d.relu ? launch_t<BF, 1, true>(s, a) : launch_t<BF, 1, false>(s, a);
+  if (d.posmajor) return d.relu ? launch_t<BF, 2, true>(s, a) : launch_t<BF, 2, false>(s, a);
+  return d.relu ? launch_t<BF, 0, true>(s, a) : launch_t<BF, 0, false>(s, a);
+}
+
+int launch_igemm(hipStream_t s, const IgemmDesc& d) {
+  const int es = d.bf16 ? 2 : 4;
+  const int bke = 128 / es;  // operand elements per k-step
+  if (d.cin % bke != 0 || d.coutpad % BN != 0 || d.cout > d.coutpad || d.kh * d.kw > 64) {
+    set_error("igemm: unsupported shape cin=%d coutpad=%d cout=%d k=%dx%d (%s)", d.cin, d.coutpad, d.cout, d.kh, d.kw,
+              d.bf16 ? "bf16" : "fp32");
     return FLM_ERR_SHAPE;
   }
   if (d.pool && ((d.h & 1) || (d.w & 1))) {
-    set_error("igemm_f32: pooled layer needs even h,w (got %dx%d)", d.h, d.w);
+    set_error("igemm: pooled layer needs even h,w (got %dx%d)", d.h, d.w);
     return FLM_ERR_SHAPE;
   }
   const long long M = (long long)d.n * d.h * d.w;
   if (M <= 0 || M > (1ll << 30)) {
-    set_error("igemm_f32: pixel count %lld out of range", M);
+    set_error("igemm: pixel count %lld out of range", M);
     return FLM_ERR_SHAPE;
   }
-  if ((long long)M * d.cin >= (1ll << 31) || (long long)d.coutpad * d.kh * d.kw * d.cin >= (1ll << 31)) {
-    set_error("igemm_f32: tensor exceeds 2^31 elements (split the batch)");
+  // byte offsets inside the kernel are 32-bit
+  if ((long long)M * d.cin * es >= (1ll << 32) || (long long)d.coutpad * d.kh * d.kw * d.cin >= (1ll << 31)) {
+    set_error("igemm: tensor exceeds the 32-bit offset range (split the batch)");
     return FLM_ERR_SHAPE;
   }
   IgemmArgs a;
   a.x = d.x; a.wt = d.wt; a.scale = d.scale; a.shift = d.shift; a.y = d.y;
+  a.out_f32 = d.bf16 ? d.out_f32 : 1;
   a.n = d.n; a.h = d.h; a.w = d.w; a.cin = d.cin; a.cout = d.cout; a.ldc = d.ldc;
   a.kh = d.kh; a.kw = d.kw; a.pad = d.pad;
   a.M = (int)M;
   a.K = d.kh * d.kw * d.cin;
   a.mtiles = cdiv(a.M, BM);
-  a.ntiles = d.coutpad / BN;
-  a.cpt = d.cin / BK;
+  a.cpt = d.cin / bke;
   a.kw_magic = (65536 + d.kw - 1) / d.kw;
-  // split-K for 1x1 layers whose tile grid cannot fill the chip (score5: 32 workgroups, 128 k-steps)
+  // split-K for 1x1 layers whose tile grid cannot fill the chip (score5: 32 workgroups at batch 64)
   a.ksplit = 1;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
-  if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && tiles <= 64 && a.cpt >= 32) {
+  if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && tiles <= 64 && a.cpt >= 32 &&
+      (!d.bf16 || d.out_f32)) {
     int ks = 256 / tiles;
     if (ks > 8) ks = 8;
     if (ks > a.cpt / 8) ks = a.cpt / 8;
@@ -458,13 +519,12 @@ int launch_igemm_f32(hipStream_t s, const IgemmDesc& d) {
   }
   // only whole N tiles that hold stored columns are launched
   a.ntiles = cdiv(d.cout, BN);
-  if (d.pool) return d.relu ? launch_t<1, true>(s, a) : launch_t<1, false>(s, a);
-  if (d.posmajor) return d.relu ? launch_t<2, true>(s, a) : launch_t<2, false>(s, a);
-  int rc = d.relu ? launch_t<0, true>(s, a) : launch_t<0, false>(s, a);
+  int rc = d.bf16 ? dispatch<true>(s, d, a) : dispatch<false>(s, d, a);
   if (rc || a.ksplit <= 1) return rc;
   const size_t total = (size_t)a.M * d.ldc;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, a.y, a.M, d.ldc, d.cout, a.ksplit, d.relu);
+  splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, reinterpret_cast<float*>(a.y), a.M, d.ldc,
+                                              d.cout, a.ksplit, d.relu);
   FLM_LAUNCH_CHECK("splitk_reduce_kernel");
   return FLM_OK;
 }

@@ -4,16 +4,18 @@
 
 namespace flm {
 
-ConvTGeom convt_geom(int C) {
+ConvTGeom convt_geom(int C, int dtype) {
   ConvTGeom g;
   g.C = C;
+  g.bf16 = dtype == FLM_BF16;
   g.MT = cdiv(C, 16);
-  if (C == 68) {  // exact path for the 68-landmark model: K = 4*68 = 17 groups of 16
-    g.Cp = 68;
-    g.G = 17;
+  if (C == 68) {
+    // exact paths for the 68-landmark model: fp32 K = 4*68 = 17 groups of 16; bf16 K = 4*72 = 9 groups of 32
+    g.Cp = g.bf16 ? 72 : 68;
+    g.G = g.bf16 ? 9 : 17;
   } else {  // generic path: channels padded to the class-tile size
     g.Cp = 16 * g.MT;
-    g.G = 4 * g.MT;
+    g.G = g.bf16 ? 2 * g.MT : 4 * g.MT;
   }
   return g;
 }
@@ -24,30 +26,32 @@ static size_t take(size_t& cur, size_t bytes) {
   return o;
 }
 
-static ConvPack conv_pack(size_t& cur, int kh, int kw, int pad, int cin, int cout, int coutpad) {
+static ConvPack conv_pack(size_t& cur, int kh, int kw, int pad, int cin, int cout, int coutpad, int es) {
   ConvPack c;
   c.kh = kh; c.kw = kw; c.pad = pad; c.cin = cin; c.cout = cout; c.coutpad = coutpad;
-  c.w = take(cur, sizeof(float) * (size_t)coutpad * kh * kw * cin);
+  c.w = take(cur, (size_t)es * coutpad * kh * kw * cin);
   c.scale = take(cur, sizeof(float) * coutpad);
   c.shift = take(cur, sizeof(float) * coutpad);
   return c;
 }
 
-Fcn8Pack fcn8_pack_layout(int C) {
+Fcn8Pack fcn8_pack_layout(int C, int dtype) {
   Fcn8Pack L;
-  L.g = convt_geom(C);
+  L.g = convt_geom(C, dtype);
+  L.dtype = dtype;
+  const int es = dtype == FLM_BF16 ? 2 : 4;
   size_t cur = 0;
   L.enc1_w = take(cur, sizeof(float) * 64 * 32);
   L.enc1_scale = take(cur, sizeof(float) * 64);
   L.enc1_shift = take(cur, sizeof(float) * 64);
-  for (int i = 0; i < 4; ++i) L.enc[i] = conv_pack(cur, 3, 3, 1, kEncF[i], kEncF[i + 1], kEncF[i + 1]);
-  L.fc6 = conv_pack(cur, 7, 7, 3, kEncF[4], kFc, kFc);
-  L.fc7 = conv_pack(cur, 1, 1, 0, kFc, kFc, kFc);
+  for (int i = 0; i < 4; ++i) L.enc[i] = conv_pack(cur, 3, 3, 1, kEncF[i], kEncF[i + 1], kEncF[i + 1], es);
+  L.fc6 = conv_pack(cur, 7, 7, 3, kEncF[4], kFc, kFc, es);
+  L.fc7 = conv_pack(cur, 1, 1, 0, kFc, kFc, kFc, es);
   // score convs write Cp channels (pad channels come out as exact zeros)
-  L.score5 = conv_pack(cur, 1, 1, 0, kFc, L.g.Cp, 128);
-  L.score4 = conv_pack(cur, 1, 1, 0, kEncF[3], L.g.Cp, 128);
-  L.score3 = conv_pack(cur, 1, 1, 0, kEncF[2], L.g.Cp, 128);
-  const size_t frag = sizeof(float) * (size_t)L.g.G * L.g.MT * 64 * 4;
+  L.score5 = conv_pack(cur, 1, 1, 0, kFc, L.g.Cp, 128, es);
+  L.score4 = conv_pack(cur, 1, 1, 0, kEncF[3], L.g.Cp, 128, es);
+  L.score3 = conv_pack(cur, 1, 1, 0, kEncF[2], L.g.Cp, 128, es);
+  const size_t frag = (size_t)16 * L.g.G * L.g.MT * 64;  // 16 bytes per lane per (group, class tile)
   L.up5 = take(cur, frag * 4);
   L.up4 = take(cur, frag * 4);
   L.up3 = take(cur, frag * 64);
@@ -56,13 +60,19 @@ Fcn8Pack fcn8_pack_layout(int C) {
 }
 
 // dst[o][(ky*kw+kx)*cin + c] = src[ky][kx][c][o]   (HWIO -> OHWI rows), zero rows for o >= cout
-__global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int kh, int kw, int cin,
+__device__ __forceinline__ void put(float* d, size_t i, float v) { d[i] = v; }
+__device__ __forceinline__ void put(unsigned short* d, size_t i, float v) {
+  d[i] = __builtin_bit_cast(unsigned short, (__bf16)v);  // round to nearest even
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ src, T* __restrict__ dst, int kh, int kw, int cin,
                                  int cout, int coutpad) {
   const size_t K = (size_t)kh * kw * cin;
   const size_t total = K * coutpad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t o = i / K, k = i % K;
-    dst[i] = (o < (size_t)cout) ? src[k * cout + o] : 0.f;
+    put(dst, i, (o < (size_t)cout) ? src[k * cout + o] : 0.f);
   }
 }
 
@@ -99,23 +109,26 @@ __global__ void pack_enc1_kernel(const float* __restrict__ src /*[3][3][3][64]*/
 
 // Transposed conv (kernel = 2s, stride s), Keras layout src[a][b][o][c] with a,b in [0,2s).
 // Output pixel (s*i0+a0, s*j0+b0) = sum_{di,dj in {0,1}} sum_c x[i0-di][j0-dj][c] * src[a0+s*di][b0+s*dj][o][c].
-// Fragment order: dst[phase=a0*s+b0][g][mt][lane][e], lane = (r = lane&15, q = lane>>4):
-//   class o = 16*mt + r, k = 16*g + 4*q + e, tap = k / Cp = 2*di+dj, c = k % Cp.
-__global__ void pack_convt_kernel(const float* __restrict__ src, float* __restrict__ dst, int s, ConvTGeom g) {
-  const size_t per_phase = (size_t)g.G * g.MT * 256;
+// Fragment order: dst[phase=a0*s+b0][g][mt][lane][e], lane = (r = lane&15, q = lane>>4), EPL = 4 (fp32) or
+// 8 (bf16) elements per lane:  class o = 16*mt + r, k = 4*EPL*g + EPL*q + e, tap = k / Cp = 2*di+dj, c = k % Cp.
+template <typename T>
+__global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__ dst, int s, ConvTGeom g) {
+  constexpr int EPL = 16 / (int)sizeof(T);
+  const size_t per_phase = (size_t)g.G * g.MT * 64 * EPL;
   const size_t total = per_phase * s * s;
   const int ks = 2 * s;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int phase = (int)(i / per_phase);
     size_t rem = i % per_phase;
-    const int e = rem & 3;
-    const int lane = (rem >> 2) & 63;
-    rem >>= 8;
+    const int e = (int)(rem % EPL);
+    rem /= EPL;
+    const int lane = (int)(rem & 63);
+    rem >>= 6;
     const int mt = (int)(rem % g.MT);
     const int gg = (int)(rem / g.MT);
     const int r = lane & 15, q = lane >> 4;
     const int o = 16 * mt + r;
-    const int k = 16 * gg + 4 * q + e;
+    const int k = 4 * EPL * gg + EPL * q + e;
     const int tap = k / g.Cp, c = k % g.Cp;
     float v = 0.f;
     if (o < g.C && c < g.C && tap < 4) {
@@ -123,18 +136,22 @@ __global__ void pack_convt_kernel(const float* __restrict__ src, float* __restri
       const int a = a0 + s * (tap >> 1), b = b0 + s * (tap & 1);
       v = src[(((size_t)a * ks + b) * g.C + o) * g.C + c];
     }
-    dst[i] = v;
+    put(dst, i, v);
   }
 }
 
-static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c, char* blob) {
+static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c, char* blob, int dtype) {
   if (!p.kernel || !p.bias) {
     set_error("flm_fcn8_pack: conv layer lacks kernel or bias");
     return FLM_ERR_ARG;
   }
   const size_t total = (size_t)c.coutpad * c.kh * c.kw * c.cin;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  pack_conv_kernel<<<blocks, 256, 0, s>>>(p.kernel, (float*)(blob + c.w), c.kh, c.kw, c.cin, c.cout, c.coutpad);
+  if (dtype == FLM_BF16)
+    pack_conv_kernel<unsigned short><<<blocks, 256, 0, s>>>(p.kernel, (unsigned short*)(blob + c.w), c.kh, c.kw, c.cin,
+                                                            c.cout, c.coutpad);
+  else
+    pack_conv_kernel<float><<<blocks, 256, 0, s>>>(p.kernel, (float*)(blob + c.w), c.kh, c.kw, c.cin, c.cout, c.coutpad);
   FLM_LAUNCH_CHECK("pack_conv_kernel");
   // pad columns of the score convs (cout = Cp > C) must stay zero: affine kernel writes zeros for o >= cout_real
   return FLM_OK;
@@ -155,7 +172,7 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
       set_error("flm_fcn8_pack: encoder level %d lacks BatchNormalization tensors", i + 2);
       return FLM_ERR_ARG;
     }
-    int rc = pack_conv(s, p.enc[i + 1], L.enc[i], blob);
+    int rc = pack_conv(s, p.enc[i + 1], L.enc[i], blob, L.dtype);
     if (rc) return rc;
     pack_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>(p.enc[i + 1], (float*)(blob + L.enc[i].scale),
                                                                    (float*)(blob + L.enc[i].shift), L.enc[i].cout,
@@ -169,7 +186,7 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
     // Keras kernels of the score convs have C output columns; the packed rows C..coutpad-1 are zero.
     ConvPack c = *it.c;
     c.cout = it.cout_real;
-    int rc = pack_conv(s, *it.p, c, blob);
+    int rc = pack_conv(s, *it.p, c, blob, L.dtype);
     if (rc) return rc;
     flm_conv_params q = *it.p;
     q.gamma = q.beta = q.mean = q.var = nullptr;
@@ -181,11 +198,15 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
     set_error("flm_fcn8_pack: transposed-conv kernels missing");
     return FLM_ERR_ARG;
   }
-  pack_convt_kernel<<<256, 256, 0, s>>>(p.up5, (float*)(blob + L.up5), 2, L.g);
-  FLM_LAUNCH_CHECK("pack_convt_kernel");
-  pack_convt_kernel<<<256, 256, 0, s>>>(p.up4, (float*)(blob + L.up4), 2, L.g);
-  FLM_LAUNCH_CHECK("pack_convt_kernel");
-  pack_convt_kernel<<<2048, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 8, L.g);
+  if (L.dtype == FLM_BF16) {
+    pack_convt_kernel<unsigned short><<<256, 256, 0, s>>>(p.up5, (unsigned short*)(blob + L.up5), 2, L.g);
+    pack_convt_kernel<unsigned short><<<256, 256, 0, s>>>(p.up4, (unsigned short*)(blob + L.up4), 2, L.g);
+    pack_convt_kernel<unsigned short><<<2048, 256, 0, s>>>(p.up3, (unsigned short*)(blob + L.up3), 8, L.g);
+  } else {
+    pack_convt_kernel<float><<<256, 256, 0, s>>>(p.up5, (float*)(blob + L.up5), 2, L.g);
+    pack_convt_kernel<float><<<256, 256, 0, s>>>(p.up4, (float*)(blob + L.up4), 2, L.g);
+    pack_convt_kernel<float><<<2048, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 8, L.g);
+  }
   FLM_LAUNCH_CHECK("pack_convt_kernel");
   return FLM_OK;
 }

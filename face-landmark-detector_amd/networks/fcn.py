@@ -29,8 +29,13 @@ def decode_mode_of(n_points: int):
 class Fcn8Model:
     model_name = "fcn_8"
 
-    def __init__(self, n_classes, input_height=416, input_width=608, channels=3):
-        # defaults as networks/fcn.py:89-90
+    def __init__(self, n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
+        # defaults as networks/fcn.py:89-90; `dtype` selects the arithmetic of the conv stack:
+        # "f32" exact fp32 (parity path) or "bf16" (bf16 operands, fp32 accumulate; BASELINE configs[2])
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
+        self._dt = _lib.FLM_F32 if dtype == "f32" else _lib.FLM_BF16
         if channels != 3:
             raise ValueError("only 3-channel input is built (reference default, fcn.py:90)")
         if input_height % 32 or input_width % 32:
@@ -88,11 +93,11 @@ class Fcn8Model:
         p.up5 = up("up5/kernel")
         p.up4 = up("up4/kernel")
         p.up3 = up("up3/kernel")
-        nbytes = lib.flm_fcn8_packed_bytes(self.n_classes, _lib.FLM_F32)
+        nbytes = lib.flm_fcn8_packed_bytes(self.n_classes, self._dt)
         if nbytes == 0:
             raise _lib.FlmError("n_classes=%d is outside what the kernels cover" % self.n_classes)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.flm_fcn8_pack(_lib.stream_ptr(), C.byref(p), self.n_classes, _lib.FLM_F32,
+        _lib.check(lib.flm_fcn8_pack(_lib.stream_ptr(), C.byref(p), self.n_classes, self._dt,
                                      _lib.ptr(packed), nbytes), "flm_fcn8_pack")
         torch.cuda.current_stream().synchronize()  # the Keras-layout copies die with `held`
         self._packed = packed
@@ -105,7 +110,7 @@ class Fcn8Model:
         if ws is None:
             lib = _lib.load()
             nbytes = lib.flm_fcn8_workspace_bytes(n, self.input_height, self.input_width, self.n_classes,
-                                                  _lib.FLM_F32, out_mode, dmode, npts)
+                                                  self._dt, out_mode, dmode, npts)
             if nbytes == 0:
                 raise _lib.FlmError("workspace query failed: %s" % lib.flm_last_error().decode())
             if len(self._ws) > 4:
@@ -152,7 +157,7 @@ class Fcn8Model:
             raise ValueError("out_tensor must be contiguous %s %s" % (shape, dt))
         ws = self._workspace(n, om, dmode, npts)
         _lib.check(lib.flm_fcn8_forward(_lib.stream_ptr(), _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
-                                        self.input_height, self.input_width, c, _lib.FLM_F32, om, dmode, npts,
+                                        self.input_height, self.input_width, c, self._dt, om, dmode, npts,
                                         float(thresh), _lib.ptr(out_tensor), _lib.ptr(ws), ws.numel()),
                    "flm_fcn8_forward")
         return out_tensor
@@ -164,11 +169,12 @@ class Fcn8Model:
         om = _OUT[out]
         dmode, npts = decode_mode_of(n_points) if om == _lib.OUT_LANDMARKS else (0, 0)
         off = lib.flm_fcn8_workspace_offset(name.encode(), n, self.input_height, self.input_width, self.n_classes,
-                                            _lib.FLM_F32, om, dmode, npts)
+                                            self._dt, om, dmode, npts)
         if off < 0:
             raise KeyError(name)
         h, w = self.input_height, self.input_width
-        cp = 68 if self.n_classes == 68 else 16 * ((self.n_classes + 15) // 16)
+        bf = self.dtype == "bf16"
+        cp = (72 if bf else 68) if self.n_classes == 68 else 16 * ((self.n_classes + 15) // 16)
         shapes = {"f1": (h // 2, w // 2, 64), "f2": (h // 4, w // 4, 128), "f3": (h // 8, w // 8, 256),
                   "f4": (h // 16, w // 16, 256), "f5": (h // 32, w // 32, 256),
                   "fc6": (h // 32, w // 32, 4096), "fc7": (h // 32, w // 32, 4096),
@@ -178,6 +184,8 @@ class Fcn8Model:
         shp = (n,) + shapes[name]
         ws = self._workspace(n, om, dmode, npts)
         cnt = int(np.prod(shp))
+        if bf and name in ("f1", "f2", "f3", "f4", "f5", "fc6", "fc7"):   # stored in the operand type
+            return ws[off:off + 2 * cnt].view(torch.bfloat16).view(shp).float()
         return ws[off:off + 4 * cnt].view(torch.float32).view(shp)
 
     def predict(self, x, batch_size=32, verbose=0):
@@ -198,10 +206,10 @@ class Fcn8Model:
         return np.concatenate(outs, axis=0)
 
 
-def fcn_8(n_classes, encoder=None, input_height=416, input_width=608, channels=3):
+def fcn_8(n_classes, encoder=None, input_height=416, input_width=608, channels=3, dtype="f32"):
     """Signature of networks/fcn.py:89-90.  Only the vanilla conv/BN/ReLU encoder is built
     (`encoder=None` or the string "vanilla"); the ImageNet backbones need a download the
     reference performs at construction time (vgg16.py:76-79 etc.) and are out of scope."""
     if encoder not in (None, "vanilla", "vanilla_encoder"):
         raise NotImplementedError("only the vanilla encoder (networks/fcn.py:10-51) is built")
-    return Fcn8Model(n_classes, input_height=input_height, input_width=input_width, channels=channels)
+    return Fcn8Model(n_classes, input_height=input_height, input_width=input_width, channels=channels, dtype=dtype)

@@ -42,6 +42,10 @@ enum flm_status {
   FLM_ERR_UNSUPPORTED = -5  /* valid request this build does not implement */
 };
 
+/* Arithmetic of the conv stack.  FLM_F32: exact fp32 on v_mfma_f32_*_f32 (the parity path).
+ * FLM_BF16: bf16 operands (weights and the activations f1..f5/fc6/fc7 stored as bf16), fp32
+ * accumulation, BatchNorm/bias/softmax/decode in fp32 (BASELINE configs[2]); inputs and outputs of
+ * flm_fcn8_forward keep the same types in both modes. */
 enum flm_dtype { FLM_F32 = 0, FLM_BF16 = 1 };
 
 /* Input formats of the forward. */
@@ -127,8 +131,8 @@ int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_c
 /* One named Conv2D layer of the model in isolation ("enc2".."enc5" with BN+ReLU+pool fused,
  * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  Used by
  * the layer parity tests and by bench.py to time the dominant kernel on its own stream. */
-int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const float* x_dev,
-                       float* y_dev, int n, int h, int w, int n_classes, int dtype);
+int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const void* x_dev,
+                       void* y_dev, int n, int h, int w, int n_classes, int dtype);
 
 /* ---- measurement hook (bench.py) --------------------------------------------------
  * When enabled, flm_fcn8_forward brackets each of its kernel launches with a hipEvent pair on

@@ -38,7 +38,9 @@ def test_size_queries_answer_without_a_gpu():
     nbytes = lib.flm_fcn8_packed_bytes(68, _lib.FLM_F32)
     # 71,361,868 conv parameters: the blob is that plus padding rows
     assert 4 * 71_361_868 < nbytes < 4 * 71_361_868 * 1.02
-    assert lib.flm_fcn8_packed_bytes(68, _lib.FLM_BF16) == 0          # not built: says so
+    nb16 = lib.flm_fcn8_packed_bytes(68, _lib.FLM_BF16)              # bf16 weights: about half
+    assert 2 * 71_361_868 < nb16 < 2 * 71_361_868 * 1.03
+    assert lib.flm_fcn8_packed_bytes(68, 7) == 0                       # unknown dtype: says so
     assert lib.flm_fcn8_packed_bytes(1000, _lib.FLM_F32) == 0
     ws = lib.flm_fcn8_workspace_bytes(64, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN, 4)
     assert ws > 64 * 264 * 264 * 68 * 4

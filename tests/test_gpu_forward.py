@@ -137,3 +137,40 @@ def test_predict_numpy_contract(flm, weights68):
     pr = model.predict(x, batch_size=2)
     assert pr.shape == (5, 40 * 72, 68) and pr.dtype == np.float32
     assert np.abs(pr - fcn_ref.fcn8_predict_ref(x, weights68)).max() <= 1e-5
+
+
+def test_bf16_forward_against_fp32_oracle(flm, weights68):
+    """BASELINE configs[2] arithmetic (bf16 operands, fp32 accumulate) at the BASELINE input size.
+
+    Not gated at 1e-4: bf16 has 8 significant bits, so every layer's inputs and weights carry a 2^-9
+    relative rounding.  What is checked: the network is the same network (intermediates within a few
+    bf16 roundings of the fp32 oracle), the probabilities stay a distribution, and the all-pixel
+    landmark centroid stays within half a pixel; the measured NME is printed for the record."""
+    from flm_amd import prediction
+    from flm_amd.networks import LANDMARKS_MODELS
+    from oracle import decode_ref, fcn_ref
+    rng = np.random.default_rng(21)
+    n, h, w, c = 2, 256, 256, 68
+    model = LANDMARKS_MODELS["fcn_8"](c, input_height=h, input_width=w, dtype="bf16")
+    model.load_weights(weights68)
+    img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    xd = torch.from_numpy(img).cuda()
+    x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in img])
+    logits_ref, inter = fcn_ref.fcn8_logits_ref(x_ref, weights68, torch.float32, return_intermediates=True)
+    probs = model.forward_device(xd, "probs").cpu().numpy()
+    for name, tol in (("f1", 1e-2), ("f2", 2e-2), ("f3", 2e-2), ("f4", 3e-2), ("f5", 3e-2), ("fc6", 4e-2),
+                      ("fc7", 4e-2), ("fuse4", 5e-2), ("seg_feats", 5e-2)):
+        got = model.intermediate(name, n, "probs").cpu().numpy()[..., : inter[name].shape[-1]]
+        assert _rel(got, inter[name]) < tol, (name, _rel(got, inter[name]))
+    probs_ref = fcn_ref.fcn8_predict_ref(x_ref, weights68)
+    assert np.abs(probs.sum(-1) - 1).max() < 1e-5
+    assert np.abs(probs - probs_ref).max() < 0.05
+    lm = prediction.predict(xd, model, n_points=0).cpu().numpy()
+    with np.errstate(all="ignore"):
+        exp = decode_ref.transfer_target_ref(probs_ref.reshape(n, 264, 264, c), 0, 0).reshape(n, c, 2)
+    err = np.linalg.norm(lm - exp, axis=-1)
+    print("bf16: probs max-abs err %.3g, all-pixel landmark max err %.3g px, NME %.3g" %
+          (np.abs(probs - probs_ref).max(), err.max(), err.mean() / 256))
+    assert err.max() < 0.5
+    cm = model.forward_device(xd, "classmap").cpu().numpy()
+    assert (cm == probs_ref.reshape(n, 264, 264, c).argmax(-1)).mean() > 0.9

@@ -9,7 +9,7 @@ from flm_amd.weights import synth_fcn8_weights
 
 lib = _lib.load()
 B = int(os.environ.get("B", "64"))
-model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=os.environ.get("DTYPE", "f32"))
 model.load_weights(synth_fcn8_weights(68, 2))
 x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
 
