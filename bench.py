@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 GFLOP_PER_FACE = 17.844          # 2*MAC over every Conv2D/Conv2DTranspose, dense
 FC6_GFLOP_PER_FACE = 6.5767      # fc6 7x7x256x4096 on 8x8, dense count (includes zero-padded taps)
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
+PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def fc6_issued_gflop(batch):
@@ -62,6 +63,67 @@ def load_traffic(layer):
             return json.load(f).get(layer)
     except (OSError, ValueError):
         return None
+
+
+def read_profile(lib):
+    """Per-layer mean duration (ms) of the launches recorded since the last reset."""
+    import numpy as np
+    layer_ms = {}
+    name = C.create_string_buffer(32)
+    ms = C.c_float()
+    i = 0
+    while lib.flm_profile_read(i, name, 32, C.byref(ms)) == 0:
+        layer_ms.setdefault(name.value.decode(), []).append(ms.value)
+        i += 1
+    return {k: float(np.mean(v)) for k, v in layer_ms.items()}
+
+
+def bf16_config3(lib, dev, batch, steps, warmup, n_points, fp32_model):
+    """BASELINE configs[2]: batch-512 bf16 conv stack (bf16 operands, fp32 accumulate) on one GPU: same step
+    as the headline (forward + softmax + decode + align); reported beside it, never as `value` (the
+    reference computes in fp32).  NME: bf16 landmarks vs the fp32 HIP path on the same crops, all-pixel
+    centroid (a top-n selection amplifies bf16 noise into pixel jumps on random-weight heatmaps)."""
+    import numpy as np
+    import torch
+    from flm_amd import _lib, alignment
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_fcn8_weights
+    H = W = 256
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=H, input_width=W, dtype="bf16")
+    model.load_weights(synth_fcn8_weights(68, seed=2))
+    crops = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (batch, H, W, 3), dtype=np.uint8)).to(dev)
+    tmpl = torch.from_numpy(alignment.canonical_template(68, H, W)).to(dev)
+    scale = (W / model.output_width, H / model.output_height)
+
+    def step():
+        lm = model.forward_device(crops, "landmarks", n_points=n_points, thresh=0.0)
+        alignment.align_device(crops, lm, tmpl, H, W, scale)
+        return lm
+
+    for _ in range(warmup):
+        step()
+    _lib.check(lib.flm_profile_enable(steps * 16 + 64), "flm_profile_enable")
+    lib.flm_profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    layers = read_profile(lib)
+    lib.flm_profile_disable()
+    fwd_ms = sum(v for k, v in layers.items() if k != "decode")
+    nb = min(64, batch)
+    a = model.forward_device(crops[:nb].contiguous(), "landmarks", n_points=0).cpu().numpy()
+    b = fp32_model.forward_device(crops[:nb].contiguous(), "landmarks", n_points=0).cpu().numpy()
+    err = np.linalg.norm(a - b, axis=-1)
+    return {"workload": "BASELINE configs[2]: batch=%d 256x256 crops, bf16 operands / fp32 accumulate, same step "
+                        "as the headline" % batch,
+            "dtype": "bf16", "faces_per_s": batch * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "forward_ms": fwd_ms, "forward_tflops": GFLOP_PER_FACE * batch / fwd_ms,
+            "frac_of_bf16_mfma_peak": GFLOP_PER_FACE * batch / fwd_ms / PEAK_BF16_TFLOPS,
+            "layer_ms": layers,
+            "landmark_nme_vs_fp32_hip": float(err.mean() / 256.0), "max_coord_err_px": float(np.abs(a - b).max())}
 
 
 def cpu_baseline(n_faces, n_points, seed):
@@ -101,6 +163,9 @@ def main():
     ap.add_argument("--n-points", type=int, default=4)
     ap.add_argument("--cpu-faces", type=int, default=16, help="sample size of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-align", action="store_true")
+    ap.add_argument("--bf16-batch", type=int, default=512,
+                    help="also time BASELINE configs[2] (bf16 operands, this many faces per step) on rank 0 "
+                         "and report it as a side object; 0 = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -162,15 +227,8 @@ def main():
         dt = float(t.item())
 
     # ---- per-launch durations recorded by HIP events inside the timed region -----------------------
-    layer_ms = {}
-    name = C.create_string_buffer(32)
-    ms = C.c_float()
-    i = 0
-    while lib.flm_profile_read(i, name, 32, C.byref(ms)) == 0:
-        layer_ms.setdefault(name.value.decode(), []).append(ms.value)
-        i += 1
+    layer_avg = read_profile(lib)
     lib.flm_profile_disable()
-    layer_avg = {k: float(np.mean(v)) for k, v in layer_ms.items()}
 
     if rank == 0:
         value = total * args.steps / dt
@@ -216,6 +274,9 @@ def main():
             err = np.linalg.norm(got - ref, axis=-1)
             rec["parity"] = {"landmark_nme_vs_oracle": float(err.mean() / 256.0),
                              "max_coord_err_px": float(np.abs(got - ref).max()), "faces": nb}
+        if args.bf16_batch > 0:
+            rec["bf16_config3"] = bf16_config3(lib, dev, args.bf16_batch, max(3, args.steps // 2), 2, args.n_points,
+                                               model)
         print(json.dumps(rec))
     if world > 1:
         dist.barrier()

@@ -40,6 +40,15 @@ struct ConvTArgs {
 
 constexpr int GCH = 6;  // k groups per LDS chunk
 
+// exp(t) for t <= 0 in the softmax.  fp32 path: the accurate library expf.  bf16 path: v_exp_f32 on
+// t*log2(e) (about 1e-6 relative, far below the bf16 rounding the logits already carry); at 16x the MFMA
+// rate the 20 accurate expf per lane per phase would cost more than the phase's matrix work.
+template <bool BF>
+__device__ __forceinline__ float softmax_exp(float t) {
+  if constexpr (BF) return __builtin_amdgcn_exp2f(t * 1.44269504088896340736f);
+  else return expf(t);
+}
+
 template <int MT, int G, bool BF>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
   constexpr int NCH = (G + GCH - 1) / GCH;
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     mx = fmaxf(mx, __shfl_xor(mx, 32));                                                           \
     p_mx = mx;                                                                                    \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
-      pv[m][e] = (16 * m + 4 * q + e < a.C) ? expf(pv[m][e] - mx) : 0.f;                          \
+      pv[m][e] = (16 * m + 4 * q + e < a.C) ? softmax_exp<BF>(pv[m][e] - mx) : 0.f;               \
   }
 #define FLM_EPI_PART2()                                                                           \
   if (a.epilogue != 0) {                                                                          \
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       sum += pv[m][e];                                                                            \
     sum += __shfl_xor(sum, 16);                                                                   \
     sum += __shfl_xor(sum, 32);                                                                   \
-    const float rs = 1.0f / sum;                                                                  \
+    const float rs = BF ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;                                \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
       pv[m][e] = pv[m][e] * rs;                                                                   \
   }
