@@ -21,6 +21,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "flm_abi_version", "flm_last_error",
     "flm_fcn8_packed_bytes", "flm_fcn8_pack",
+    "flm_fcn32_packed_bytes", "flm_fcn32_pack", "flm_fcn32_workspace_bytes", "flm_fcn32_forward",
     "flm_fcn8_workspace_bytes", "flm_fcn8_forward", "flm_fcn8_workspace_offset", "flm_fcn8_run_layer",
     "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
@@ -60,6 +61,14 @@ def _declare(lib):
     lib.flm_fcn8_workspace_bytes.argtypes = [i] * 8
     lib.flm_fcn8_forward.restype = i
     lib.flm_fcn8_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp, sz]
+    lib.flm_fcn32_packed_bytes.restype = sz
+    lib.flm_fcn32_packed_bytes.argtypes = [i, i]
+    lib.flm_fcn32_pack.restype = i
+    lib.flm_fcn32_pack.argtypes = [vp, C.POINTER(Fcn8Params), i, i, vp, sz]
+    lib.flm_fcn32_workspace_bytes.restype = sz
+    lib.flm_fcn32_workspace_bytes.argtypes = [i] * 8
+    lib.flm_fcn32_forward.restype = i
+    lib.flm_fcn32_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp, sz]
     lib.flm_fcn8_workspace_offset.restype = C.c_int64
     lib.flm_fcn8_workspace_offset.argtypes = [C.c_char_p] + [i] * 8
     lib.flm_fcn8_run_layer.restype = i

@@ -52,7 +52,8 @@ static size_t take(size_t& cur, size_t bytes) {
   return o;
 }
 
-Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points) {
+Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points,
+                      int fcn32) {
   Fcn8Ws W;
   const ConvTGeom g = convt_geom(C, dtype);
   const size_t es = dtype == FLM_BF16 ? 2 : 4;  // activations f1..f5, fc6, fc7 are stored in the operand type
@@ -71,8 +72,8 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   W.seg = take(cur, sizeof(float) * (size_t)n * h3 * w3 * g.Cp);
   W.splitk_bytes = sizeof(float) * 8 * (size_t)n * h5 * w5 * g.Cp;
   W.splitk = take(cur, W.splitk_bytes);
-  W.oh = h + 8;
-  W.ow = w + 8;
+  W.oh = h + (fcn32 ? 32 : 8);  // (h/32 - 1)*32 + 64 (fcn.py:145) vs (h/8 - 1)*8 + 16 (fcn.py:121)
+  W.ow = w + (fcn32 ? 32 : 8);
   W.probs = SIZE_MAX;
   W.decode = SIZE_MAX;
   if (out_mode == FLM_OUT_LANDMARKS) {
@@ -190,13 +191,15 @@ int flm_profile_disable(void) {
 }
 const char* flm_last_error(void) { return g_err; }
 
-size_t flm_fcn8_packed_bytes(int n_classes, int dtype) {
+static size_t packed_bytes_impl(int n_classes, int dtype, int fcn32) {
   if ((dtype != FLM_F32 && dtype != FLM_BF16) || n_classes < 1 || n_classes > kMaxClasses) return 0;
-  return fcn8_pack_layout(n_classes, dtype).total;
+  return fcn8_pack_layout(n_classes, dtype, fcn32).total;
 }
+size_t flm_fcn8_packed_bytes(int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, 0); }
+size_t flm_fcn32_packed_bytes(int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, 1); }
 
-int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
-                  size_t packed_bytes) {
+static int pack_impl(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
+                     size_t packed_bytes, int fcn32) {
   if (!p || !packed_dev) {
     set_error("flm_fcn8_pack: null argument");
     return FLM_ERR_ARG;
@@ -209,18 +212,31 @@ int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, 
     set_error("flm_fcn8_pack: n_classes must be in [1,%d]", kMaxClasses);
     return FLM_ERR_SHAPE;
   }
-  const Fcn8Pack L = fcn8_pack_layout(n_classes, dtype);
+  const Fcn8Pack L = fcn8_pack_layout(n_classes, dtype, fcn32);
   if (packed_bytes < L.total) {
     set_error("flm_fcn8_pack: packed buffer too small (%zu < %zu)", packed_bytes, L.total);
     return FLM_ERR_WORKSPACE;
   }
   return launch_pack_fcn8(static_cast<hipStream_t>(stream), *p, n_classes, L, static_cast<char*>(packed_dev));
 }
+int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
+                  size_t packed_bytes) {
+  return pack_impl(stream, p, n_classes, dtype, packed_dev, packed_bytes, 0);
+}
+int flm_fcn32_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
+                   size_t packed_bytes) {
+  return pack_impl(stream, p, n_classes, dtype, packed_dev, packed_bytes, 1);
+}
 
 size_t flm_fcn8_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
                                 int n_points) {
   if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
-  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points).total;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, 0).total;
+}
+size_t flm_fcn32_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                                 int n_points) {
+  if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, 1).total;
 }
 
 int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype, int out_mode,
@@ -237,9 +253,9 @@ int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_c
   return -1;
 }
 
-int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
-                     int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
-                     void* out_dev, void* workspace_dev, size_t workspace_bytes) {
+static int forward_impl(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
+                        int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
+                        void* out_dev, void* workspace_dev, size_t workspace_bytes, int fcn32) {
   if (!packed_dev || !x_dev || !out_dev || !workspace_dev) {
     set_error("flm_fcn8_forward: null argument");
     return FLM_ERR_ARG;
@@ -250,13 +266,13 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
     set_error("flm_fcn8_forward: unknown output mode %d", out_mode);
     return FLM_ERR_ARG;
   }
-  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points);
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points, fcn32);
   if (workspace_bytes < W.total) {
     set_error("flm_fcn8_forward: workspace too small (%zu < %zu)", workspace_bytes, W.total);
     return FLM_ERR_WORKSPACE;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const Fcn8Pack L = fcn8_pack_layout(C, dtype);
+  const Fcn8Pack L = fcn8_pack_layout(C, dtype, fcn32);
   const int bf = dtype == FLM_BF16;
   const char* blob = static_cast<const char*>(packed_dev);
   char* ws = static_cast<char*>(workspace_dev);
@@ -295,6 +311,10 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
   rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0, dtype, /*out_f32*/ 1,
                   reinterpret_cast<float*>(ws + W.splitk), W.splitk_bytes); }
   if (rc) return rc;
+  ConvTDesc t;
+  t.g = L.g;
+  t.n = n;
+  if (!fcn32) {
   // skip branches: score4 on f4 -> fuse4 buffer, score3 on f3 -> seg buffer, then the transposed
   // convs add themselves onto those (crop keeps the top-left window, fcn.py:76-84)
   { ProfScope ps(s, "score4");
@@ -303,9 +323,6 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
   { ProfScope ps(s, "score3");
   rc = conv_layer(s, blob, L.score3, f[2], seg, n, h3, w3, 0, 0, 0, dtype, 1); }
   if (rc) return rc;
-  ConvTDesc t;
-  t.g = L.g;
-  t.n = n;
   // up5 (fcn.py:104) + crop + Add (fcn.py:110-112), in place on fuse4
   t.x = score5; t.wf = blob + L.up5; t.skip = fuse4; t.y = fuse4;
   t.hi = h5; t.wi = w5; t.ho = h4; t.wo = w4; t.s = 2; t.ldy = L.g.Cp; t.epilogue = 0;
@@ -318,9 +335,13 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
   { ProfScope ps(s, "up4");
   rc = launch_convt(s, t); }
   if (rc) return rc;
-  // up3 (fcn.py:121) + softmax (networks/utils.py:30) / argmax (prediction.py:209)
-  t.x = seg; t.wf = blob + L.up3; t.skip = nullptr;
-  t.hi = h3; t.wi = w3; t.ho = W.oh; t.wo = W.ow; t.s = 8; t.ldy = C;
+  }  // !fcn32
+  // last upsampling + softmax (networks/utils.py:30) / argmax (prediction.py:209):
+  //   fcn_8 : Conv2DTranspose(16x16, s8) on seg_feats  (fcn.py:121)
+  //   fcn_32: Conv2DTranspose(64x64, s32) on the 1x1 classifier output  (fcn.py:143-146)
+  t.wf = blob + L.up3; t.skip = nullptr; t.ho = W.oh; t.wo = W.ow; t.ldy = C;
+  if (fcn32) { t.x = score5; t.hi = h5; t.wi = w5; t.s = 32; }
+  else { t.x = seg; t.hi = h3; t.wi = w3; t.s = 8; }
   if (out_mode == FLM_OUT_LOGITS || out_mode == FLM_OUT_PROBS) {
     t.y = out_dev;
     t.epilogue = (out_mode == FLM_OUT_PROBS) ? 1 : 0;
@@ -372,6 +393,19 @@ int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* 
   if (!strcmp(layer, "score3")) return conv_layer(s, blob, L.score3, x_dev, y_dev, n, h, w, 0, 0, 0, dtype, 1);
   set_error("flm_fcn8_run_layer: unknown layer '%s'", layer);
   return FLM_ERR_ARG;
+}
+
+int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
+                     int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
+                     void* out_dev, void* workspace_dev, size_t workspace_bytes) {
+  return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
+                      out_dev, workspace_dev, workspace_bytes, 0);
+}
+int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
+                      int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
+                      void* out_dev, void* workspace_dev, size_t workspace_bytes) {
+  return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
+                      out_dev, workspace_dev, workspace_bytes, 1);
 }
 
 int flm_preprocess(flm_stream_t stream, const uint8_t* img, int n, int h, int w, int norm, float* out) {

@@ -60,9 +60,10 @@ struct Fcn8Pack {
   size_t up5, up4, up3;  // [s*s phases][G][MT][64 lanes][16 bytes: 4 fp32 or 8 bf16]
   ConvTGeom g;
   int dtype;
+  int fcn32;  // fcn_32 variant: no skip branches, one 64x64 stride-32 transposed conv in the up3 slot
   size_t total;
 };
-Fcn8Pack fcn8_pack_layout(int C, int dtype);
+Fcn8Pack fcn8_pack_layout(int C, int dtype, int fcn32 = 0);
 
 // Workspace of the forward (offsets in bytes).
 struct Fcn8Ws {
@@ -75,7 +76,8 @@ struct Fcn8Ws {
   size_t total;
   int oh, ow;
 };
-Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points);
+Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points,
+                      int fcn32 = 0);
 
 // ---- kernel launchers (each returns FLM_OK or an error) --------------------------------------
 int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8Pack& L, char* blob);

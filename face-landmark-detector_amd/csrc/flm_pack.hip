@@ -35,10 +35,11 @@ static ConvPack conv_pack(size_t& cur, int kh, int kw, int pad, int cin, int cou
   return c;
 }
 
-Fcn8Pack fcn8_pack_layout(int C, int dtype) {
+Fcn8Pack fcn8_pack_layout(int C, int dtype, int fcn32) {
   Fcn8Pack L;
   L.g = convt_geom(C, dtype);
   L.dtype = dtype;
+  L.fcn32 = fcn32;
   const int es = dtype == FLM_BF16 ? 2 : 4;
   size_t cur = 0;
   L.enc1_w = take(cur, sizeof(float) * 64 * 32);
@@ -52,9 +53,9 @@ Fcn8Pack fcn8_pack_layout(int C, int dtype) {
   L.score4 = conv_pack(cur, 1, 1, 0, kEncF[3], L.g.Cp, 128, es);
   L.score3 = conv_pack(cur, 1, 1, 0, kEncF[2], L.g.Cp, 128, es);
   const size_t frag = (size_t)16 * L.g.G * L.g.MT * 64;  // 16 bytes per lane per (group, class tile)
-  L.up5 = take(cur, frag * 4);
-  L.up4 = take(cur, frag * 4);
-  L.up3 = take(cur, frag * 64);
+  L.up5 = take(cur, fcn32 ? 0 : frag * 4);
+  L.up4 = take(cur, fcn32 ? 0 : frag * 4);
+  L.up3 = take(cur, frag * (fcn32 ? 1024 : 64));  // fcn_32: 32x32 phases of the 64x64 kernel
   L.total = cur;
   return L;
 }
@@ -182,7 +183,8 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
   struct Item { const flm_conv_params* p; const ConvPack* c; int cout_real; };
   const Item items[5] = {{&p.fc6, &L.fc6, kFc}, {&p.fc7, &L.fc7, kFc}, {&p.score5, &L.score5, C},
                          {&p.score4, &L.score4, C}, {&p.score3, &L.score3, C}};
-  for (const Item& it : items) {
+  for (int ii = 0; ii < (L.fcn32 ? 3 : 5); ++ii) {
+    const Item& it = items[ii];
     // Keras kernels of the score convs have C output columns; the packed rows C..coutpad-1 are zero.
     ConvPack c = *it.c;
     c.cout = it.cout_real;
@@ -193,6 +195,18 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
     pack_affine_kernel<<<cdiv(c.coutpad, 256), 256, 0, s>>>(q, (float*)(blob + c.scale), (float*)(blob + c.shift),
                                                             it.cout_real, c.coutpad);
     FLM_LAUNCH_CHECK("pack_affine_kernel");
+  }
+  if (L.fcn32) {  // fcn.py:145-146: one Conv2DTranspose(C, 64x64, stride 32), passed in the up3 slot
+    if (!p.up3) {
+      set_error("flm_fcn32_pack: transposed-conv kernel missing");
+      return FLM_ERR_ARG;
+    }
+    if (L.dtype == FLM_BF16)
+      pack_convt_kernel<unsigned short><<<4096, 256, 0, s>>>(p.up3, (unsigned short*)(blob + L.up3), 32, L.g);
+    else
+      pack_convt_kernel<float><<<4096, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 32, L.g);
+    FLM_LAUNCH_CHECK("pack_convt_kernel");
+    return FLM_OK;
   }
   if (!p.up5 || !p.up4 || !p.up3) {
     set_error("flm_fcn8_pack: transposed-conv kernels missing");

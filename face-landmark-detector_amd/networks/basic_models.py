@@ -6,7 +6,7 @@ registry lists only ImageNet-backbone variants (whose constructors download weig
 broken 'default'; it has no entry for the vanilla FCN-8 the hot path is built on, so this
 registry adds 'fcn_8' and points 'default' at it.
 """
-from .fcn import fcn_8
+from .fcn import fcn_8, fcn_32
 
 
 def _not_built(name, why):
@@ -19,6 +19,7 @@ _BACKBONE = "its encoder fetches ImageNet weights at construction (no network); 
 
 LANDMARKS_MODELS = {
     "fcn_8": fcn_8,
+    "fcn_32": fcn_32,
     "default": fcn_8,
     "fcn_8_resnet50": _not_built("fcn_8_resnet50", _BACKBONE),
     "fcn_8_mobilenet": _not_built("fcn_8_mobilenet", _BACKBONE),

@@ -28,6 +28,8 @@ def decode_mode_of(n_points: int):
 
 class Fcn8Model:
     model_name = "fcn_8"
+    _api = "fcn8"          # prefix of the C entry points (flm_fcn8_* / flm_fcn32_*)
+    _grid_growth = 8       # output grid = input + 8: (H/8 - 1)*8 + 16, fcn.py:121-124 has no final crop
 
     def __init__(self, n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
         # defaults as networks/fcn.py:89-90; `dtype` selects the arithmetic of the conv stack:
@@ -44,9 +46,8 @@ class Fcn8Model:
         self.n_classes = int(n_classes)
         self.input_height = int(input_height)
         self.input_width = int(input_width)
-        # (H/8 - 1)*8 + 16 = H + 8: fcn.py:121-124 has no final crop
-        self.output_height = self.input_height + 8
-        self.output_width = self.input_width + 8
+        self.output_height = self.input_height + self._grid_growth
+        self.output_width = self.input_width + self._grid_growth
         self._packed = None
         self._ws = {}
 
@@ -63,7 +64,7 @@ class Fcn8Model:
         import torch
         lib = _lib.load()
         dev = _lib.require_gpu()
-        W.check_params(params, self.n_classes)
+        W.check_params(params, self.n_classes, arch=self.model_name)
         held = []
 
         def up(name):
@@ -88,17 +89,20 @@ class Fcn8Model:
         p.fc6 = conv("fc6", False)
         p.fc7 = conv("fc7", False)
         p.score5 = conv("score5", False)
-        p.score4 = conv("score4", False)
-        p.score3 = conv("score3", False)
-        p.up5 = up("up5/kernel")
-        p.up4 = up("up4/kernel")
-        p.up3 = up("up3/kernel")
-        nbytes = lib.flm_fcn8_packed_bytes(self.n_classes, self._dt)
+        if self._api == "fcn8":
+            p.score4 = conv("score4", False)
+            p.score3 = conv("score3", False)
+            p.up5 = up("up5/kernel")
+            p.up4 = up("up4/kernel")
+            p.up3 = up("up3/kernel")
+        else:  # fcn_32: the single 64x64 stride-32 transposed conv travels in the up3 slot
+            p.up3 = up("up32/kernel")
+        nbytes = getattr(lib, "flm_%s_packed_bytes" % self._api)(self.n_classes, self._dt)
         if nbytes == 0:
             raise _lib.FlmError("n_classes=%d is outside what the kernels cover" % self.n_classes)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.flm_fcn8_pack(_lib.stream_ptr(), C.byref(p), self.n_classes, self._dt,
-                                     _lib.ptr(packed), nbytes), "flm_fcn8_pack")
+        _lib.check(getattr(lib, "flm_%s_pack" % self._api)(_lib.stream_ptr(), C.byref(p), self.n_classes, self._dt,
+                                                           _lib.ptr(packed), nbytes), "flm_%s_pack" % self._api)
         torch.cuda.current_stream().synchronize()  # the Keras-layout copies die with `held`
         self._packed = packed
 
@@ -109,8 +113,8 @@ class Fcn8Model:
         ws = self._ws.get(key)
         if ws is None:
             lib = _lib.load()
-            nbytes = lib.flm_fcn8_workspace_bytes(n, self.input_height, self.input_width, self.n_classes,
-                                                  self._dt, out_mode, dmode, npts)
+            nbytes = getattr(lib, "flm_%s_workspace_bytes" % self._api)(n, self.input_height, self.input_width,
+                                                                        self.n_classes, self._dt, out_mode, dmode, npts)
             if nbytes == 0:
                 raise _lib.FlmError("workspace query failed: %s" % lib.flm_last_error().decode())
             if len(self._ws) > 4:
@@ -156,7 +160,7 @@ class Fcn8Model:
         elif tuple(out_tensor.shape) != shape or out_tensor.dtype != dt or not out_tensor.is_contiguous():
             raise ValueError("out_tensor must be contiguous %s %s" % (shape, dt))
         ws = self._workspace(n, om, dmode, npts)
-        _lib.check(lib.flm_fcn8_forward(_lib.stream_ptr(), _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
+        _lib.check(getattr(lib, "flm_%s_forward" % self._api)(_lib.stream_ptr(), _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
                                         self.input_height, self.input_width, c, self._dt, om, dmode, npts,
                                         float(thresh), _lib.ptr(out_tensor), _lib.ptr(ws), ws.numel()),
                    "flm_fcn8_forward")
@@ -204,6 +208,25 @@ class Fcn8Model:
             xd = torch.from_numpy(xb).to(dev)
             outs.append(self.forward_device(xd, "probs").cpu().numpy())
         return np.concatenate(outs, axis=0)
+
+
+class Fcn32Model(Fcn8Model):
+    """fcn_32 (networks/fcn.py:129-150): same encoder and head, one Conv2DTranspose(C, 64x64, stride 32);
+    output grid = input + 32.  Weight container: the fcn_8 tensors without score4/score3/up5/up4/up3,
+    plus `up32/kernel` (64,64,C,C); `score5/*` is the 1x1 classifier the reference names "seg_feats"."""
+    model_name = "fcn_32"
+    _api = "fcn32"
+    _grid_growth = 32
+
+    def intermediate(self, name, n, out="probs", n_points=0):
+        raise NotImplementedError("workspace views are exposed for fcn_8 only")
+
+
+def fcn_32(n_classes, encoder=None, input_height=416, input_width=608, channels=3, dtype="f32"):
+    """Signature of networks/fcn.py:129-130 (vanilla encoder only, as fcn_8)."""
+    if encoder not in (None, "vanilla", "vanilla_encoder"):
+        raise NotImplementedError("only the vanilla encoder (networks/fcn.py:10-51) is built")
+    return Fcn32Model(n_classes, input_height=input_height, input_width=input_width, channels=channels, dtype=dtype)
 
 
 def fcn_8(n_classes, encoder=None, input_height=416, input_width=608, channels=3, dtype="f32"):

@@ -23,6 +23,14 @@ ENC_FILTERS = (64, 128, 256, 256, 256)  # networks/fcn.py:13,34,43
 FC_WIDTH = 4096                          # networks/fcn.py:98,100
 
 
+def fcn32_param_shapes(n_classes: int, channels: int = 3) -> dict:
+    """fcn_32 (networks/fcn.py:129-150): encoder + fc6 + fc7 + 1x1 classifier + one 64x64/s32 transposed conv."""
+    s8 = fcn8_param_shapes(n_classes, channels)
+    shapes = {k: v for k, v in s8.items() if k.split("/")[0] not in ("score4", "score3", "up5", "up4", "up3")}
+    shapes["up32/kernel"] = (64, 64, n_classes, n_classes)
+    return shapes
+
+
 def fcn8_param_shapes(n_classes: int, channels: int = 3) -> dict:
     shapes = {}
     cin = channels
@@ -46,6 +54,17 @@ def fcn8_param_shapes(n_classes: int, channels: int = 3) -> dict:
     shapes["up4/kernel"] = (4, 4, n_classes, n_classes)
     shapes["up3/kernel"] = (16, 16, n_classes, n_classes)
     return shapes
+
+
+def synth_fcn32_weights(n_classes: int = 68, seed: int = 2, channels: int = 3) -> dict:
+    """Seeded synthetic fcn_32 parameters: the fcn_8 set's shared tensors + a scaled 64x64 kernel."""
+    p8 = synth_fcn8_weights(n_classes, seed, channels)
+    p = {k: v for k, v in p8.items() if k in fcn32_param_shapes(n_classes, channels)}
+    rng = np.random.default_rng(seed + 1000)
+    # each output pixel sums 2x2 taps of n_classes inputs
+    p["up32/kernel"] = (rng.standard_normal((64, 64, n_classes, n_classes), dtype=np.float32)
+                        * np.float32(np.sqrt(1.0 / (4 * n_classes))))
+    return p
 
 
 def synth_fcn8_weights(n_classes: int = 68, seed: int = 2, channels: int = 3) -> dict:
@@ -103,8 +122,8 @@ def load_weights_file(path: str) -> dict:
         return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
 
 
-def check_params(params: dict, n_classes: int, channels: int = 3) -> None:
-    want = fcn8_param_shapes(n_classes, channels)
+def check_params(params: dict, n_classes: int, channels: int = 3, arch: str = "fcn_8") -> None:
+    want = fcn32_param_shapes(n_classes, channels) if arch == "fcn_32" else fcn8_param_shapes(n_classes, channels)
     missing = sorted(set(want) - set(params))
     if missing:
         raise KeyError("weight container lacks tensors: %s" % ", ".join(missing))

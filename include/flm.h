@@ -128,6 +128,20 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
 int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype,
                                   int out_mode, int decode_mode, int n_points);
 
+/* ---- fcn_32 (networks/fcn.py:129-150) ------------------------------------------------------------
+ * Same encoder and head; no skip branches; one Conv2DTranspose(C, 64x64, stride 32) then the
+ * softmax: output grid H' = H+32, W' = W+32.  Parameters: flm_fcn8_params with `up3` holding the
+ * (64,64,C,C) kernel; score4, score3, up5, up4 are ignored.  Same contracts as the fcn8 calls. */
+size_t flm_fcn32_packed_bytes(int n_classes, int dtype);
+int flm_fcn32_pack(flm_stream_t stream, const flm_fcn8_params* params_dev_ptrs, int n_classes, int dtype,
+                   void* packed_dev, size_t packed_bytes);
+size_t flm_fcn32_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode,
+                                 int decode_mode, int n_points);
+int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format,
+                      int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                      int n_points, float thresh, void* out_dev, void* workspace_dev,
+                      size_t workspace_bytes);
+
 /* One named Conv2D layer of the model in isolation ("enc2".."enc5" with BN+ReLU+pool fused,
  * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  Used by
  * the layer parity tests and by bench.py to time the dominant kernel on its own stream. */

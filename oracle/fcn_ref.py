@@ -129,6 +129,25 @@ def fcn8_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, return_int
     return logits.numpy()
 
 
+def fcn32_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
+    """networks/fcn.py:129-146 up to the softmax: encoder, fc6, fc7, 1x1 classifier ("seg_feats", :143-144),
+    Conv2DTranspose(C, 64x64, stride 32, no bias) (:145-146).  Output grid (H/32 - 1)*32 + 64 = H + 32."""
+    x = _t(x_nhwc, dtype).permute(0, 3, 1, 2).contiguous()
+    f5 = vanilla_encoder_ref(x, p, dtype)[4]
+    o = torch.relu(_conv(f5, p["fc6/kernel"], p["fc6/bias"], 3, dtype))   # fcn.py:138
+    o = torch.relu(_conv(o, p["fc7/kernel"], p["fc7/bias"], 0, dtype))    # fcn.py:140
+    o = _conv(o, p["score5/kernel"], p["score5/bias"], 0, dtype)          # fcn.py:143-144
+    o = _convT(o, p["up32/kernel"], 32, dtype)                            # fcn.py:145-146
+    return o.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def fcn32_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
+    """fcn_32 + get_segmentation_model (networks/utils.py:22-31): [N, H'*W', C] probabilities."""
+    logits = torch.from_numpy(fcn32_logits_ref(x_nhwc, p, dtype))
+    n, h, w, c = logits.shape
+    return torch.softmax(logits.reshape(n, h * w, c), dim=-1).numpy()
+
+
 def fcn8_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
     """`model.predict` of the model built by fcn_8 + get_segmentation_model
     (networks/utils.py:22-31): Reshape((H'*W', C)) then softmax over the last axis.

@@ -174,3 +174,22 @@ def test_bf16_forward_against_fp32_oracle(flm, weights68):
     assert err.max() < 0.5
     cm = model.forward_device(xd, "classmap").cpu().numpy()
     assert (cm == probs_ref.reshape(n, 264, 264, c).argmax(-1)).mean() > 0.9
+
+
+def test_fcn32_forward(flm, weights68):
+    """fcn_32 (networks/fcn.py:129-150): 64x64 stride-32 transposed conv, output grid H+32."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_fcn32_weights
+    from oracle import fcn_ref
+    rng = np.random.default_rng(32)
+    for (n, h, w, c) in ((2, 64, 96, 68), (1, 256, 256, 68), (2, 64, 64, 5)):
+        params = synth_fcn32_weights(c, seed=2)
+        model = LANDMARKS_MODELS["fcn_32"](c, input_height=h, input_width=w)
+        assert (model.output_height, model.output_width, model.model_name) == (h + 32, w + 32, "fcn_32")
+        model.load_weights(params)
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in img])
+        exp = fcn_ref.fcn32_predict_ref(x_ref, params)
+        got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
+        assert got.shape == exp.shape == (n, (h + 32) * (w + 32), c)
+        assert np.abs(got - exp).max() <= 1e-5, (n, h, w, c, np.abs(got - exp).max())

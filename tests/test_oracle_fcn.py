@@ -140,3 +140,21 @@ def test_preprocess_and_classmap():
     pr[2] = [0.5, 0.5, 0]  # tie -> first maximum
     cm = fcn_ref.class_map_ref(pr, 2, 3, 3)
     assert cm.dtype == np.int64 and cm[0, 2] == 0 and cm[1, 1] == 1
+
+
+def test_fcn32_oracle_matches_naive():
+    p = tiny_params()
+    rng = np.random.default_rng(3)
+    p["up32/kernel"] = rng.standard_normal((64, 64, 5, 5)).astype(np.float32) * 0.1
+    x = rng.standard_normal((1, 64, 96, 3)).astype(np.float32)
+    got = fcn_ref.fcn32_logits_ref(x, p, torch.float64)
+    assert got.shape == (1, 96, 128, 5)     # (H/32 - 1)*32 + 64 = H + 32
+    xx = x[0].astype(np.float64)
+    for i in range(1, 6):
+        n = "enc%d" % i
+        xx = n_pool(np.maximum(n_bn(n_conv(xx, p[n + "/kernel"], p[n + "/bias"], 1), p, n), 0))
+    o = np.maximum(n_conv(xx, p["fc6/kernel"], p["fc6/bias"], 3), 0)
+    o = np.maximum(n_conv(o, p["fc7/kernel"], p["fc7/bias"], 0), 0)
+    o = n_conv(o, p["score5/kernel"], p["score5/bias"], 0)
+    o = n_convT(o, p["up32/kernel"], 32)
+    np.testing.assert_allclose(got[0], o, rtol=1e-9, atol=1e-9)
