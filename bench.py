@@ -263,7 +263,7 @@ def main():
                         "frac_of_f32_mfma_peak": fwd_tflops / PEAK_F32_TFLOPS,
                         "faces_per_s_forward_only": 1e3 * B / fwd_ms, "layer_ms": layer_avg},
         }
-        if args.cpu_faces > 0:
+        if args.cpu_faces > 0 and world == 1:   # CPU leg: rank 0 at N=1 only
             base, lm_cpu, crops_cpu = cpu_baseline(args.cpu_faces, args.n_points, seed=1)
             rec["cpu_baseline"] = base
             # the same crops on the GPU: landmark NME vs the oracle (NME := mean ||p - p_ref|| / 256)
@@ -274,7 +274,7 @@ def main():
             err = np.linalg.norm(got - ref, axis=-1)
             rec["parity"] = {"landmark_nme_vs_oracle": float(err.mean() / 256.0),
                              "max_coord_err_px": float(np.abs(got - ref).max()), "faces": nb}
-        if args.bf16_batch > 0:
+        if args.bf16_batch > 0 and world == 1:
             rec["bf16_config3"] = bf16_config3(lib, dev, args.bf16_batch, max(3, args.steps // 2), 2, args.n_points,
                                                model)
         print(json.dumps(rec))

@@ -147,6 +147,13 @@ class Fcn8Model:
             raise ValueError("input dtype must be uint8 (BGR) or float32 (preprocessed)")
         n = int(x.shape[0])
         om = _OUT[out]
+        if n == 0:  # empty batch: nothing to launch
+            oh0, ow0, c0 = self.output_height, self.output_width, self.n_classes
+            shp0, dt0 = {_lib.OUT_PROBS: ((0, oh0 * ow0, c0), torch.float32),
+                         _lib.OUT_LOGITS: ((0, oh0, ow0, c0), torch.float32),
+                         _lib.OUT_CLASSMAP: ((0, oh0, ow0), torch.int32),
+                         _lib.OUT_LANDMARKS: ((0, c0, 2), torch.float64)}[om]
+            return torch.empty(shp0, dtype=dt0, device=x.device)
         dmode, npts = decode_mode_of(n_points) if om == _lib.OUT_LANDMARKS else (0, 0)
         oh, ow, c = self.output_height, self.output_width, self.n_classes
         shape, dt = {
@@ -200,6 +207,8 @@ class Fcn8Model:
         x = np.asarray(x)
         if x.ndim != 4:
             raise ValueError("predict expects [N,H,W,3]")
+        if x.shape[0] == 0:
+            return np.zeros((0, self.output_height * self.output_width, self.n_classes), np.float32)
         outs = []
         for i in range(0, x.shape[0], batch_size):
             xb = np.ascontiguousarray(x[i:i + batch_size])

@@ -22,6 +22,8 @@ def decode_device(hm, n_points=4, thresh=0.0, out=None):
     if hm.dim() != 4 or hm.dtype != torch.float32 or not hm.is_cuda or not hm.is_contiguous():
         raise ValueError("decode_device needs a contiguous CUDA float32 [N,H,W,L] tensor")
     n, h, w, l = [int(v) for v in hm.shape]
+    if n == 0:
+        return torch.empty((0, l, 2), dtype=torch.float64, device=hm.device)
     mode, npts = (_lib.DECODE_ALL, 0) if n_points < 1 else (_lib.DECODE_TOPN, int(n_points))
     nbytes = lib.flm_decode_workspace_bytes(n, h, w, l, mode, npts)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=hm.device)

@@ -90,3 +90,21 @@ def test_keypts_predict_returns_class_map(setup, tmp_path):
     assert diff.mean() < 1e-3
     import os
     assert os.path.getsize(out) > 0
+
+
+def test_empty_and_ragged_batches(setup):
+    """Edge cases: an empty batch launches nothing; a batch that is not a multiple of any tile size
+    (N = 3) and the single-face batch agree with each other face by face."""
+    prediction, model, params = setup
+    from flm_amd.utils import metrics
+    empty = torch.empty((0, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    assert tuple(model.forward_device(empty, "probs").shape) == (0, 264 * 264, 68)
+    assert tuple(model.forward_device(empty, "landmarks", n_points=4).shape) == (0, 68, 2)
+    assert model.predict(np.zeros((0, 256, 256, 3), np.float32)).shape == (0, 264 * 264, 68)
+    assert metrics.transfer_target(np.zeros((0, 8, 8, 3), np.float32)).shape == (0, 6)
+    rng = np.random.default_rng(9)
+    crops = torch.from_numpy(rng.integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)).cuda()
+    a = model.forward_device(crops, "landmarks", n_points=4).clone()
+    for i in range(3):   # the same face alone gives bit-identical landmarks (no cross-face coupling)
+        b = model.forward_device(crops[i:i + 1].contiguous(), "landmarks", n_points=4)
+        assert torch.equal(a[i], b[0])
