@@ -71,7 +71,7 @@ def transfer_target(y_pred, thresh=0, n_points=64, as_shipped=None):
     else:
         hm = _to_device(np.asarray(y_pred))
     out = decode_device(hm, n_points, thresh)
-    return out.reshape(out.shape[0], -1).cpu().numpy()
+    return out.reshape(out.shape[0], 2 * out.shape[1]).cpu().numpy()
 
 
 def get_RMSE(y_pred_xy, y_train_xy, pick_not_NA):
