@@ -38,7 +38,7 @@ struct ConvTArgs {
   int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
 };
 
-constexpr int GCH = 6;  // k groups per LDS chunk
+constexpr int GCH_F32 = 6, GCH_BF16 = 3;  // k groups per LDS chunk (bf16: smaller chunks, fewer staging registers)
 
 // exp(t) for t <= 0 in the softmax.  fp32 path: the accurate library expf.  bf16 path: v_exp_f32 on
 // t*log2(e) (about 1e-6 relative, far below the bf16 rounding the logits already carry); at 16x the MFMA
@@ -49,8 +49,9 @@ __device__ __forceinline__ float softmax_exp(float t) {
   else return expf(t);
 }
 
-template <int MT, int G, bool BF>
+template <int MT, int G, bool BF, int NT>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
+  constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr int NCH = (G + GCH - 1) / GCH;
   constexpr int CHUNK_F4 = GCH * MT * 64;             // float4 per full chunk
   constexpr int NLD = (CHUNK_F4 + 255) / 256;         // staging loads per thread
@@ -62,25 +63,35 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   const int a0 = blockIdx.y;
   const int s = a.s;
 
-  // ---- this lane's input position ---------------------------------------------------------------
-  const int p = blockIdx.x * 64 + wave * 16 + r;
-  const bool pvalid = p < a.P;
-  const int pp = pvalid ? p : 0;
+  // ---- this lane's NT input positions (NT pixel tiles of 16 per wave: the phase's weights, streamed once
+  //      per workgroup, then serve 64*NT positions) --------------------------------------------------
   const int wi1 = a.wi + 1, hi1 = a.hi + 1;
-  const int j0 = pp % wi1, i0 = (pp / wi1) % hi1, img = pp / (wi1 * hi1);
+  bool pvalid[NT];
+  int i0[NT], j0[NT], img[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int p = (blockIdx.x * 4 + wave) * 16 * NT + nt * 16 + r;
+    pvalid[nt] = p < a.P;
+    const int pp = pvalid[nt] ? p : 0;
+    j0[nt] = pp % wi1;
+    i0[nt] = (pp / wi1) % hi1;
+    img[nt] = pp / (wi1 * hi1);
+  }
 
   // ---- X fragments ------------------------------------------------------------------------------------
   //   fp32: xf[g] = x[tap(k4)][c(k4)..+3],  k4 = 16g + 4q   (4 floats)
   //   bf16: xf[g] = bf16(x[tap(k8)][c(k8)..+7]), k8 = 32g + 8q (8 floats converted, 16 bytes)
-  float4 xf[G];
+  float4 xf[NT][G];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     constexpr int EPL = BF ? 8 : 4;
     const int k0 = 4 * EPL * g + EPL * q;
     const int tap = k0 / a.Cp, c = k0 % a.Cp;
-    const int ii = i0 - (tap >> 1), jj = j0 - (tap & 1);
-    const bool ok = pvalid && tap < 4 && (unsigned)ii < (unsigned)a.hi && (unsigned)jj < (unsigned)a.wi;
-    const size_t off = ok ? (((size_t)img * a.hi + ii) * a.wi + jj) * a.Cp + c : 0;
+    const int ii = i0[nt] - (tap >> 1), jj = j0[nt] - (tap & 1);
+    const bool ok = pvalid[nt] && tap < 4 && (unsigned)ii < (unsigned)a.hi && (unsigned)jj < (unsigned)a.wi;
+    const size_t off = ok ? (((size_t)img[nt] * a.hi + ii) * a.wi + jj) * a.Cp + c : 0;
     // (component-wise selects: a float4 struct select goes through scratch memory)
     const float km = ok ? 1.f : 0.f;
     if constexpr (BF) {
@@ -91,10 +102,10 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       t[2] = (__bf16)(ok ? v0.z : 0.f); t[3] = (__bf16)(ok ? v0.w : 0.f);
       t[4] = (__bf16)(ok ? v1.x : 0.f); t[5] = (__bf16)(ok ? v1.y : 0.f);
       t[6] = (__bf16)(ok ? v1.z : 0.f); t[7] = (__bf16)(ok ? v1.w : 0.f);
-      xf[g] = __builtin_bit_cast(float4, t);
+      xf[nt][g] = __builtin_bit_cast(float4, t);
     } else {
       const float4 v = *reinterpret_cast<const float4*>(a.x + off);
-      xf[g] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      xf[nt][g] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
     (void)km;
   }
@@ -144,45 +155,49 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   //   part 1: class maximum (in-lane + two xor-shuffles), e = exp(x - max)
   //   part 2: sum, one reciprocal, p = e * (1/sum)
   //   part 3: stores (probabilities / class map / raw + skip)
-  f32x4 pv[MT];  // previous phase's accumulator, transformed in place by the parts
+  f32x4 pv[NT][MT];  // previous phase's accumulators, transformed in place by the parts
 #pragma unroll
-  for (int m = 0; m < MT; ++m) pv[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float p_mx = 0.f;
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pv[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #define FLM_EPI_PART1()                                                                           \
   if (a.epilogue != 0) {                                                                          \
-    float mx = -3.402823466e38f;                                                                  \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
-      if (16 * m + 4 * q + e < a.C) mx = fmaxf(mx, pv[m][e]);                                     \
-    mx = fmaxf(mx, __shfl_xor(mx, 16));                                                           \
-    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                           \
-    p_mx = mx;                                                                                    \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
-      pv[m][e] = (16 * m + 4 * q + e < a.C) ? softmax_exp<BF>(pv[m][e] - mx) : 0.f;               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
+      float mx = -3.402823466e38f;                                                                \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+        if (16 * m + 4 * q + e < a.C) mx = fmaxf(mx, pv[nt][m][e]);                               \
+      mx = fmaxf(mx, __shfl_xor(mx, 16));                                                         \
+      mx = fmaxf(mx, __shfl_xor(mx, 32));                                                         \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+        pv[nt][m][e] = (16 * m + 4 * q + e < a.C) ? softmax_exp<BF>(pv[nt][m][e] - mx) : 0.f;     \
+    }                                                                                             \
   }
 #define FLM_EPI_PART2()                                                                           \
   if (a.epilogue != 0) {                                                                          \
-    float sum = 0.f;                                                                              \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
-      sum += pv[m][e];                                                                            \
-    sum += __shfl_xor(sum, 16);                                                                   \
-    sum += __shfl_xor(sum, 32);                                                                   \
-    const float rs = BF ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;                                \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
-      pv[m][e] = pv[m][e] * rs;                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
+      float sum = 0.f;                                                                            \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+        sum += pv[nt][m][e];                                                                      \
+      sum += __shfl_xor(sum, 16);                                                                 \
+      sum += __shfl_xor(sum, 32);                                                                 \
+      const float rs = BF ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;                              \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+        pv[nt][m][e] = pv[nt][m][e] * rs;                                                         \
+    }                                                                                             \
   }
 #define FLM_EPI_PART3(B0)                                                                         \
-  {                                                                                               \
-    const int oy = s * i0 + a0, ox = s * j0 + (B0);                                               \
-    const bool ovalid = pvalid && oy < a.ho && ox < a.wo;                                         \
-    const size_t opix = ((size_t)img * a.ho + oy) * a.wo + ox;                                    \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                             \
+    const int oy = s * i0[nt] + a0, ox = s * j0[nt] + (B0);                                       \
+    const bool ovalid = pvalid[nt] && oy < a.ho && ox < a.wo;                                     \
+    const size_t opix = ((size_t)img[nt] * a.ho + oy) * a.wo + ox;                                \
     if (a.epilogue == 0) {                                                                        \
       if (ovalid) {                                                                               \
         float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;                                  \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                          \
           const int c4 = 16 * m + 4 * q;                                                          \
           if (c4 < a.ldy) { /* ldy is a multiple of 4 here (score buffers, Cp channels) */        \
-            float4 v = make_float4(pv[m][0], pv[m][1], pv[m][2], pv[m][3]);                       \
+            float4 v = make_float4(pv[nt][m][0], pv[nt][m][1], pv[nt][m][2], pv[nt][m][3]);                       \
             if (a.skip) {                                                                         \
               const float4 sk = *reinterpret_cast<const float4*>(a.skip + opix * a.Cp + c4);     \
               v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;                                 \
@@ -198,12 +213,12 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
           _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                        \
             const int c4 = 16 * m + 4 * q;                                                        \
             if (c4 < a.C)                                                                         \
-              *reinterpret_cast<float4*>(y + c4) = make_float4(pv[m][0], pv[m][1], pv[m][2], pv[m][3]); \
+              *reinterpret_cast<float4*>(y + c4) = make_float4(pv[nt][m][0], pv[nt][m][1], pv[nt][m][2], pv[nt][m][3]); \
           }                                                                                       \
         } else {                                                                                  \
           _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
             const int c = 16 * m + 4 * q + e;                                                     \
-            if (c < a.C) y[c] = pv[m][e];                                                         \
+            if (c < a.C) y[c] = pv[nt][m][e];                                                         \
           }                                                                                       \
         }                                                                                         \
       }                                                                                           \
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       int bi = 0x7fffffff;                                                                        \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
         const int c = 16 * m + 4 * q + e; /* ascending within a lane */                           \
-        if (c < a.C && pv[m][e] > bv) { bv = pv[m][e]; bi = c; }                                  \
+        if (c < a.C && pv[nt][m][e] > bv) { bv = pv[nt][m][e]; bi = c; }                                  \
       }                                                                                           \
       _Pragma("unroll") for (int sh = 16; sh <= 32; sh <<= 1) {                                   \
         const float ov = __shfl_xor(bv, sh);                                                      \
@@ -226,9 +241,11 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 
   int seq = 0;
   for (int b0 = 0; b0 < s; ++b0) {
-    f32x4 acc[MT];
+    f32x4 acc[NT][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -249,19 +266,30 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #pragma unroll
           for (int m = 0; m < MT; ++m) af[m] = wl[(gl * MT + m) * 64 + lane];
           if constexpr (BF) {
-            const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[g]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, acc[m], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+              const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, acc[nt][m],
+                                                                      0, 0, 0);
+            }
           } else {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[g].x, acc[m], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[g].y, acc[m], 0, 0, 0);
+              for (int m = 0; m < MT; ++m)
+                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, acc[nt][m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[g].z, acc[m], 0, 0, 0);
+              for (int m = 0; m < MT; ++m)
+                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, acc[nt][m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[g].w, acc[m], 0, 0, 0);
+              for (int m = 0; m < MT; ++m)
+                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, acc[nt][m], 0, 0, 0);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, acc[nt][m], 0, 0, 0);
+            }
           }
         }
       }
@@ -270,13 +298,14 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       ++seq;
     }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) pv[m] = acc[m];
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) pv[nt][m] = acc[nt][m];
   }
   // drain: the last phase's epilogue
   FLM_EPI_PART1()
   FLM_EPI_PART2()
   FLM_EPI_PART3(s - 1)
-  (void)p_mx;
 }
 
 #undef FLM_EPI_PART1
@@ -288,17 +317,18 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #undef FLM_LD1
 #undef FLM_ST1
 
-template <int MT, int G, bool BF>
+template <int MT, int G, bool BF, int NT = 1>
 static int launch_t(hipStream_t st, const ConvTArgs& a) {
+  constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64;
   static bool attr_done = false;
   if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF>),
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  dim3 grid(cdiv(a.P, 64), a.s);
-  convt_kernel<MT, G, BF><<<grid, 256, lds, st>>>(a);
+  dim3 grid(cdiv(a.P, 64 * NT), a.s);
+  convt_kernel<MT, G, BF, NT><<<grid, 256, lds, st>>>(a);
   FLM_LAUNCH_CHECK("convt_kernel");
   return FLM_OK;
 }
@@ -319,7 +349,9 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     return FLM_ERR_SHAPE;
   }
   if (d.g.bf16) {
-    if (d.g.C == 68 && d.g.G == 9) return launch_t<5, 9, true>(st, a);
+    // two pixel tiles per wave: at 16x the matrix rate the phase weights (45 KiB per 64 positions) are the
+    // stream to economise
+    if (d.g.C == 68 && d.g.G == 9) return launch_t<5, 9, true, 2>(st, a);
     switch (d.g.MT) {
       case 1: return launch_t<1, 2, true>(st, a);
       case 2: return launch_t<2, 4, true>(st, a);
