@@ -50,6 +50,10 @@ class Fcn8Model:
         self.output_width = self.input_width + self._grid_growth
         self._packed = None
         self._ws = {}
+        # the kernels address activations with 32-bit byte offsets: the largest tensor (f1, 64 channels at
+        # half resolution) bounds the faces per launch; larger batches are processed in slices
+        es = 4 if dtype == "f32" else 2
+        self.max_batch = max(1, (2 ** 32 - 1) // ((self.input_height // 2) * (self.input_width // 2) * 64 * es) - 1)
 
     # ---- weights ------------------------------------------------------------------------------
     def load_weights(self, path_or_params):
@@ -166,6 +170,11 @@ class Fcn8Model:
             out_tensor = torch.empty(shape, dtype=dt, device=x.device)
         elif tuple(out_tensor.shape) != shape or out_tensor.dtype != dt or not out_tensor.is_contiguous():
             raise ValueError("out_tensor must be contiguous %s %s" % (shape, dt))
+        if n > self.max_batch:   # slice the batch (contiguous outputs, same stream)
+            for lo in range(0, n, self.max_batch):
+                hi = min(n, lo + self.max_batch)
+                self.forward_device(x[lo:hi], out, n_points, thresh, out_tensor[lo:hi])
+            return out_tensor
         ws = self._workspace(n, om, dmode, npts)
         _lib.check(getattr(lib, "flm_%s_forward" % self._api)(_lib.stream_ptr(), _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
                                         self.input_height, self.input_width, c, self._dt, om, dmode, npts,

@@ -108,3 +108,21 @@ def test_empty_and_ragged_batches(setup):
     for i in range(3):   # the same face alone gives bit-identical landmarks (no cross-face coupling)
         b = model.forward_device(crops[i:i + 1].contiguous(), "landmarks", n_points=4)
         assert torch.equal(a[i], b[0])
+
+
+def test_batches_beyond_the_launch_limit_are_sliced(setup):
+    """`max_batch` (32-bit offsets inside the kernels) is honoured by slicing: same results as one launch."""
+    prediction, model, params = setup
+    rng = np.random.default_rng(10)
+    crops = torch.from_numpy(rng.integers(0, 256, (5, 256, 256, 3), dtype=np.uint8)).cuda()
+    whole = model.forward_device(crops, "landmarks", n_points=4).clone()
+    assert model.max_batch >= 512
+    saved = model.max_batch
+    try:
+        model.max_batch = 2
+        sliced = model.forward_device(crops, "landmarks", n_points=4)
+        cm = model.forward_device(crops, "classmap")
+    finally:
+        model.max_batch = saved
+    assert torch.equal(whole, sliced)
+    assert tuple(cm.shape) == (5, 264, 264)
