@@ -22,6 +22,7 @@ EXPORTS = [
     "flm_abi_version", "flm_last_error",
     "flm_fcn8_packed_bytes", "flm_fcn8_pack",
     "flm_fcn32_packed_bytes", "flm_fcn32_pack", "flm_fcn32_workspace_bytes", "flm_fcn32_forward",
+    "flm_fcn_packed_bytes", "flm_fcn_pack", "flm_fcn_workspace_bytes", "flm_fcn_forward",
     "flm_fcn8_workspace_bytes", "flm_fcn8_forward", "flm_fcn8_workspace_offset", "flm_fcn8_run_layer",
     "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
@@ -43,6 +44,14 @@ class Fcn8Params(C.Structure):
                 ("score5", ConvParams), ("score4", ConvParams), ("score3", ConvParams),
                 ("up5", C.c_void_p), ("up4", C.c_void_p), ("up3", C.c_void_p)]
 
+
+class FcnParams(C.Structure):
+    _fields_ = [("enc", C.POINTER(ConvParams)), ("n_enc", C.c_int), ("fc6", ConvParams), ("fc7", ConvParams),
+                ("score5", ConvParams), ("score4", ConvParams), ("score3", ConvParams),
+                ("up5", C.c_void_p), ("up4", C.c_void_p), ("up3", C.c_void_p)]
+
+
+ARCH_FCN8, ARCH_FCN32, ARCH_FCN8_VGG, ARCH_FCN32_VGG = 0, 1, 2, 3
 
 _lib = None
 
@@ -69,6 +78,14 @@ def _declare(lib):
     lib.flm_fcn32_workspace_bytes.argtypes = [i] * 8
     lib.flm_fcn32_forward.restype = i
     lib.flm_fcn32_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp, sz]
+    lib.flm_fcn_packed_bytes.restype = sz
+    lib.flm_fcn_packed_bytes.argtypes = [i, i, i]
+    lib.flm_fcn_pack.restype = i
+    lib.flm_fcn_pack.argtypes = [vp, i, C.POINTER(FcnParams), i, i, vp, sz]
+    lib.flm_fcn_workspace_bytes.restype = sz
+    lib.flm_fcn_workspace_bytes.argtypes = [i] * 9
+    lib.flm_fcn_forward.restype = i
+    lib.flm_fcn_forward.argtypes = [vp, i, vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp, sz]
     lib.flm_fcn8_workspace_offset.restype = C.c_int64
     lib.flm_fcn8_workspace_offset.argtypes = [C.c_char_p] + [i] * 8
     lib.flm_fcn8_run_layer.restype = i

@@ -53,17 +53,21 @@ static size_t take(size_t& cur, size_t bytes) {
 }
 
 Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points,
-                      int fcn32) {
+                      int arch) {
   Fcn8Ws W;
   const ConvTGeom g = convt_geom(C, dtype);
-  const size_t es = dtype == FLM_BF16 ? 2 : 4;  // activations f1..f5, fc6, fc7 are stored in the operand type
+  const ArchSpec A = arch_spec(arch);
+  const size_t es = dtype == FLM_BF16 ? 2 : 4;  // encoder activations, fc6, fc7 are stored in the operand type
   size_t cur = 0;
   int hh = h, ww = w;
-  for (int i = 0; i < 5; ++i) {
-    hh >>= 1;
-    ww >>= 1;
-    W.f[i] = take(cur, es * (size_t)n * hh * ww * kEncF[i]);
+  for (int i = 0; i < A.n_enc; ++i) {
+    if (A.enc[i].pool) {
+      hh >>= 1;
+      ww >>= 1;
+    }
+    W.act[i] = take(cur, es * (size_t)n * hh * ww * A.enc[i].cout);
   }
+  for (int k = 0; k < 5; ++k) W.f[k] = W.act[A.f_idx[k]];
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
   W.fc6 = take(cur, es * (size_t)n * h5 * w5 * kFc);
   W.fc7 = take(cur, es * (size_t)n * h5 * w5 * kFc);
@@ -72,8 +76,8 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   W.seg = take(cur, sizeof(float) * (size_t)n * h3 * w3 * g.Cp);
   W.splitk_bytes = sizeof(float) * 8 * (size_t)n * h5 * w5 * g.Cp;
   W.splitk = take(cur, W.splitk_bytes);
-  W.oh = h + (fcn32 ? 32 : 8);  // (h/32 - 1)*32 + 64 (fcn.py:145) vs (h/8 - 1)*8 + 16 (fcn.py:121)
-  W.ow = w + (fcn32 ? 32 : 8);
+  W.oh = h + (A.fcn32 ? 32 : 8);  // (h/32 - 1)*32 + 64 (fcn.py:145) vs (h/8 - 1)*8 + 16 (fcn.py:121)
+  W.ow = w + (A.fcn32 ? 32 : 8);
   W.probs = SIZE_MAX;
   W.decode = SIZE_MAX;
   if (out_mode == FLM_OUT_LANDMARKS) {
@@ -191,15 +195,21 @@ int flm_profile_disable(void) {
 }
 const char* flm_last_error(void) { return g_err; }
 
-static size_t packed_bytes_impl(int n_classes, int dtype, int fcn32) {
+static size_t packed_bytes_impl(int n_classes, int dtype, int arch) {
   if ((dtype != FLM_F32 && dtype != FLM_BF16) || n_classes < 1 || n_classes > kMaxClasses) return 0;
-  return fcn8_pack_layout(n_classes, dtype, fcn32).total;
+  if (!arch_spec(arch).valid) return 0;
+  return fcn8_pack_layout(n_classes, dtype, arch).total;
 }
-size_t flm_fcn8_packed_bytes(int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, 0); }
-size_t flm_fcn32_packed_bytes(int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, 1); }
+size_t flm_fcn_packed_bytes(int arch, int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, arch); }
+size_t flm_fcn8_packed_bytes(int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, FLM_ARCH_FCN8); }
+size_t flm_fcn32_packed_bytes(int n_classes, int dtype) { return packed_bytes_impl(n_classes, dtype, FLM_ARCH_FCN32); }
 
-static int pack_impl(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
-                     size_t packed_bytes, int fcn32) {
+static int pack_impl(flm_stream_t stream, const flm_fcn_params* p, int n_classes, int dtype, void* packed_dev,
+                     size_t packed_bytes, int arch) {
+  if (!arch_spec(arch).valid) {
+    set_error("flm_fcn_pack: unknown architecture %d", arch);
+    return FLM_ERR_ARG;
+  }
   if (!p || !packed_dev) {
     set_error("flm_fcn8_pack: null argument");
     return FLM_ERR_ARG;
@@ -212,31 +222,58 @@ static int pack_impl(flm_stream_t stream, const flm_fcn8_params* p, int n_classe
     set_error("flm_fcn8_pack: n_classes must be in [1,%d]", kMaxClasses);
     return FLM_ERR_SHAPE;
   }
-  const Fcn8Pack L = fcn8_pack_layout(n_classes, dtype, fcn32);
+  const Fcn8Pack L = fcn8_pack_layout(n_classes, dtype, arch);
   if (packed_bytes < L.total) {
     set_error("flm_fcn8_pack: packed buffer too small (%zu < %zu)", packed_bytes, L.total);
     return FLM_ERR_WORKSPACE;
   }
-  return launch_pack_fcn8(static_cast<hipStream_t>(stream), *p, n_classes, L, static_cast<char*>(packed_dev));
+  return launch_pack_fcn(static_cast<hipStream_t>(stream), *p, n_classes, L, static_cast<char*>(packed_dev));
+}
+static flm_fcn_params from_fcn8(const flm_fcn8_params* p) {
+  flm_fcn_params q;
+  q.enc = p->enc;
+  q.n_enc = 5;
+  q.fc6 = p->fc6; q.fc7 = p->fc7; q.score5 = p->score5; q.score4 = p->score4; q.score3 = p->score3;
+  q.up5 = p->up5; q.up4 = p->up4; q.up3 = p->up3;
+  return q;
+}
+int flm_fcn_pack(flm_stream_t stream, int arch, const flm_fcn_params* p, int n_classes, int dtype, void* packed_dev,
+                 size_t packed_bytes) {
+  return pack_impl(stream, p, n_classes, dtype, packed_dev, packed_bytes, arch);
 }
 int flm_fcn8_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
                   size_t packed_bytes) {
-  return pack_impl(stream, p, n_classes, dtype, packed_dev, packed_bytes, 0);
+  if (!p) {
+    set_error("flm_fcn8_pack: null argument");
+    return FLM_ERR_ARG;
+  }
+  const flm_fcn_params q = from_fcn8(p);
+  return pack_impl(stream, &q, n_classes, dtype, packed_dev, packed_bytes, FLM_ARCH_FCN8);
 }
 int flm_fcn32_pack(flm_stream_t stream, const flm_fcn8_params* p, int n_classes, int dtype, void* packed_dev,
                    size_t packed_bytes) {
-  return pack_impl(stream, p, n_classes, dtype, packed_dev, packed_bytes, 1);
+  if (!p) {
+    set_error("flm_fcn32_pack: null argument");
+    return FLM_ERR_ARG;
+  }
+  const flm_fcn_params q = from_fcn8(p);
+  return pack_impl(stream, &q, n_classes, dtype, packed_dev, packed_bytes, FLM_ARCH_FCN32);
 }
 
 size_t flm_fcn8_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
                                 int n_points) {
   if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
-  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, 0).total;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, FLM_ARCH_FCN8).total;
 }
 size_t flm_fcn32_workspace_bytes(int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
                                  int n_points) {
   if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
-  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, 1).total;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, FLM_ARCH_FCN32).total;
+}
+size_t flm_fcn_workspace_bytes(int arch, int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                               int n_points) {
+  if (!arch_spec(arch).valid || check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, arch).total;
 }
 
 int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype, int out_mode,
@@ -255,7 +292,13 @@ int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_c
 
 static int forward_impl(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
                         int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
-                        void* out_dev, void* workspace_dev, size_t workspace_bytes, int fcn32) {
+                        void* out_dev, void* workspace_dev, size_t workspace_bytes, int arch) {
+  const ArchSpec A = arch_spec(arch);
+  if (!A.valid) {
+    set_error("flm_fcn_forward: unknown architecture %d", arch);
+    return FLM_ERR_ARG;
+  }
+  const int fcn32 = A.fcn32;
   if (!packed_dev || !x_dev || !out_dev || !workspace_dev) {
     set_error("flm_fcn8_forward: null argument");
     return FLM_ERR_ARG;
@@ -266,13 +309,13 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     set_error("flm_fcn8_forward: unknown output mode %d", out_mode);
     return FLM_ERR_ARG;
   }
-  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points, fcn32);
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points, arch);
   if (workspace_bytes < W.total) {
     set_error("flm_fcn8_forward: workspace too small (%zu < %zu)", workspace_bytes, W.total);
     return FLM_ERR_WORKSPACE;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const Fcn8Pack L = fcn8_pack_layout(C, dtype, fcn32);
+  const Fcn8Pack L = fcn8_pack_layout(C, dtype, arch);
   const int bf = dtype == FLM_BF16;
   const char* blob = static_cast<const char*>(packed_dev);
   char* ws = static_cast<char*>(workspace_dev);
@@ -284,20 +327,24 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   float* fuse4 = reinterpret_cast<float*>(ws + W.fuse4);
   float* seg = reinterpret_cast<float*>(ws + W.seg);
 
-  // encoder (networks/fcn.py:10-51)
-  { ProfScope ps(s, "enc1");
+  // encoder: vanilla (networks/fcn.py:10-51) or VGG16 (networks/vgg16.py:27-72)
+  static const char* const enc_names[kMaxEnc] = {"enc1", "enc2", "enc3", "enc4", "enc5", "enc6", "enc7",
+                                                 "enc8", "enc9", "enc10", "enc11", "enc12", "enc13"};
+  { ProfScope ps(s, enc_names[0]);
   rc = launch_enc1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
                    reinterpret_cast<const float*>(blob + L.enc1_scale),
-                   reinterpret_cast<const float*>(blob + L.enc1_shift), f[0], bf); }
+                   reinterpret_cast<const float*>(blob + L.enc1_shift), ws + W.act[0], bf, A.enc[0].pool); }
   if (rc) return rc;
-  int hh = h / 2, ww = w / 2;
-  for (int i = 0; i < 4; ++i) {
-    static const char* const enc_names[4] = {"enc2", "enc3", "enc4", "enc5"};
+  int hh = A.enc[0].pool ? h / 2 : h, ww = A.enc[0].pool ? w / 2 : w;
+  for (int i = 1; i < A.n_enc; ++i) {
     { ProfScope ps(s, enc_names[i]);
-    rc = conv_layer(s, blob, L.enc[i], f[i], f[i + 1], n, hh, ww, /*relu*/ 1, /*pool*/ 1, 0, dtype); }
+    rc = conv_layer(s, blob, L.enc[i], ws + W.act[i - 1], ws + W.act[i], n, hh, ww, /*relu*/ 1, A.enc[i].pool, 0,
+                    dtype); }
     if (rc) return rc;
-    hh /= 2;
-    ww /= 2;
+    if (A.enc[i].pool) {
+      hh /= 2;
+      ww /= 2;
+    }
   }
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
   // head (fcn.py:98-103); Dropout is the identity at inference
@@ -385,7 +432,7 @@ int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* 
   const char* blob = static_cast<const char*>(packed_dev);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!strncmp(layer, "enc", 3) && layer[3] >= '2' && layer[3] <= '5' && layer[4] == 0)
-    return conv_layer(s, blob, L.enc[layer[3] - '2'], x_dev, y_dev, n, h, w, 1, 1, 0, dtype);
+    return conv_layer(s, blob, L.enc[layer[3] - '1'], x_dev, y_dev, n, h, w, 1, 1, 0, dtype);
   if (!strcmp(layer, "fc6")) return conv_layer(s, blob, L.fc6, x_dev, y_dev, n, h, w, 1, 0, 1, dtype);
   if (!strcmp(layer, "fc7")) return conv_layer(s, blob, L.fc7, x_dev, y_dev, n, h, w, 1, 0, 0, dtype);
   if (!strcmp(layer, "score5")) return conv_layer(s, blob, L.score5, x_dev, y_dev, n, h, w, 0, 0, 0, dtype, 1);
@@ -399,13 +446,19 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
                      int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
                      void* out_dev, void* workspace_dev, size_t workspace_bytes) {
   return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
-                      out_dev, workspace_dev, workspace_bytes, 0);
+                      out_dev, workspace_dev, workspace_bytes, FLM_ARCH_FCN8);
+}
+int flm_fcn_forward(flm_stream_t stream, int arch, const void* packed_dev, const void* x_dev, int in_format, int n,
+                    int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
+                    void* out_dev, void* workspace_dev, size_t workspace_bytes) {
+  return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
+                      out_dev, workspace_dev, workspace_bytes, arch);
 }
 int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
                       int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
                       void* out_dev, void* workspace_dev, size_t workspace_bytes) {
   return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
-                      out_dev, workspace_dev, workspace_bytes, 1);
+                      out_dev, workspace_dev, workspace_bytes, FLM_ARCH_FCN32);
 }
 
 int flm_preprocess(flm_stream_t stream, const uint8_t* img, int n, int h, int w, int norm, float* out) {

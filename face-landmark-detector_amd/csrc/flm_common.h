@@ -30,9 +30,23 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 constexpr float kBnEps = 1e-3f;  // keras BatchNormalization default epsilon
 
 // ---- architecture constants (networks/fcn.py:13,34,43,98,100) ------------------------------
-constexpr int kEncF[5] = {64, 128, 256, 256, 256};
 constexpr int kFc = 4096;
 constexpr int kMaxClasses = 96;
+constexpr int kMaxEnc = 13;
+
+// Encoder description: every layer is Conv2D 3x3 'same' + (BatchNorm) + ReLU (+ MaxPool 2x2).
+struct EncLayer {
+  int cin, cout, bn, pool;
+};
+struct ArchSpec {
+  int n_enc;
+  EncLayer enc[kMaxEnc];
+  int f_idx[5];  // index of the layer whose (pooled) output is f1..f5
+  int fcn32;     // one 64x64 stride-32 transposed conv instead of the FCN-8 skip decoder
+  int valid;
+};
+// FLM_ARCH_FCN8 / FCN32: vanilla_encoder (networks/fcn.py:10-51); *_VGG: get_vgg_encoder (networks/vgg16.py:17-81)
+ArchSpec arch_spec(int arch);
 
 // Geometry of the transposed-conv kernels for a class count C.
 struct ConvTGeom {
@@ -55,19 +69,21 @@ struct ConvPack {
 struct Fcn8Pack {
   size_t enc1_w;  // float [64][32], k = ky*9+kx*3+c (c in RGB order), zero for k >= 27
   size_t enc1_scale, enc1_shift;
-  ConvPack enc[4];  // enc2..enc5
+  ConvPack enc[kMaxEnc];  // enc[i] packs encoder layer i for i >= 1 (layer 0 is the 3-channel first conv)
   ConvPack fc6, fc7, score5, score4, score3;
   size_t up5, up4, up3;  // [s*s phases][G][MT][64 lanes][16 bytes: 4 fp32 or 8 bf16]
   ConvTGeom g;
   int dtype;
-  int fcn32;  // fcn_32 variant: no skip branches, one 64x64 stride-32 transposed conv in the up3 slot
+  int arch;
+  ArchSpec spec;
   size_t total;
 };
-Fcn8Pack fcn8_pack_layout(int C, int dtype, int fcn32 = 0);
+Fcn8Pack fcn8_pack_layout(int C, int dtype, int arch = 0);
 
 // Workspace of the forward (offsets in bytes).
 struct Fcn8Ws {
-  size_t f[5];
+  size_t act[kMaxEnc];  // output of every encoder layer
+  size_t f[5];          // = act[spec.f_idx[k]]
   size_t fc6, fc7, score5, fuse4, seg;
   size_t splitk;  // split-K partial sums of the score convs
   size_t splitk_bytes;
@@ -77,13 +93,13 @@ struct Fcn8Ws {
   int oh, ow;
 };
 Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points,
-                      int fcn32 = 0);
+                      int arch = 0);
 
 // ---- kernel launchers (each returns FLM_OK or an error) --------------------------------------
-int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8Pack& L, char* blob);
+int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pack& L, char* blob);
 
 int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
-                const float* scale, const float* shift, void* f1, int out_bf16);
+                const float* scale, const float* shift, void* f1, int out_bf16, int pool);
 
 struct IgemmDesc {
   const void* x;       // [n,h,w,cin] fp32, or bf16 when `bf16`

@@ -25,7 +25,7 @@ __device__ __forceinline__ int koff_of(int k) {  // halo offset of patch element
   return (k < 27) ? (k / 9) * HALO_STRIDE + (k % 9) : -1;
 }
 
-template <bool U8, bool OBF>
+template <bool U8, bool OBF, bool POOL>
 __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin, const float* __restrict__ w1p,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    void* __restrict__ f1, int n, int h, int w) {
@@ -101,37 +101,61 @@ __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin,
       }
     }
 
-    // epilogue: BN, ReLU, 2x2 max over registers 4g..4g+3; pooled pixel xp0 + 8*wave + 2g + lh
+    // epilogue: scale/shift (BN or bias), ReLU, then either the 2x2 max over registers 4g..4g+3 (pooled pixel
+    // xp0 + 8*wave + 2g + lh) or, for an un-pooled first layer (VGG block1_conv1), every conv output itself
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float v = 0.f;  // ReLU floor
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v = fmaxf(v, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
         const int xp = xp0 + 8 * wave + 2 * g + lh;
-        if (xp < wp) {
-          const size_t o = (((size_t)img * hp + yp) * wp + xp) * 64 + 32 * j + lr;
-          if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
-          else reinterpret_cast<float*>(f1)[o] = v;
+        if (POOL) {
+          float v = 0.f;  // ReLU floor
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v = fmaxf(v, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
+          if (xp < wp) {
+            const size_t o = (((size_t)img * hp + yp) * wp + xp) * 64 + 32 * j + lr;
+            if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            else reinterpret_cast<float*>(f1)[o] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {  // row 4g+e of the quad block: (dy, dx) = (e>>1, e&1)
+            const float v = fmaxf(0.f, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
+            const int y = 2 * yp + (e >> 1), x = 2 * xp + (e & 1);
+            if (xp < wp) {
+              const size_t o = (((size_t)img * h + y) * w + x) * 64 + 32 * j + lr;
+              if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
+              else reinterpret_cast<float*>(f1)[o] = v;
+            }
+          }
         }
       }
   }
 }
 
+template <bool U8>
+static void launch_u(hipStream_t s, int blocks, const void* x, const float* w1p, const float* scale, const float* shift,
+                     void* f1, int n, int h, int w, int out_bf16, int pool) {
+  if (out_bf16) {
+    if (pool) enc1_kernel<U8, true, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+    else enc1_kernel<U8, true, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  } else {
+    if (pool) enc1_kernel<U8, false, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+    else enc1_kernel<U8, false, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  }
+}
+
 int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
-                const float* scale, const float* shift, void* f1, int out_bf16) {
+                const float* scale, const float* shift, void* f1, int out_bf16, int pool) {
   if ((h & 1) || (w & 1)) {
     set_error("enc1: h,w must be even");
     return FLM_ERR_SHAPE;
   }
   const int blocks = n * (h >> 1);
   if (in_format == FLM_IN_U8_BGR) {
-    if (out_bf16) enc1_kernel<true, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-    else enc1_kernel<true, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+    launch_u<true>(s, blocks, x, w1p, scale, shift, f1, n, h, w, out_bf16, pool);
   } else if (in_format == FLM_IN_F32_RGB) {
-    if (out_bf16) enc1_kernel<false, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-    else enc1_kernel<false, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+    launch_u<false>(s, blocks, x, w1p, scale, shift, f1, n, h, w, out_bf16, pool);
   } else {
     set_error("enc1: unknown input format %d", in_format);
     return FLM_ERR_ARG;

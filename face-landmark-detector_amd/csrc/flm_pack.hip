@@ -20,6 +20,38 @@ ConvTGeom convt_geom(int C, int dtype) {
   return g;
 }
 
+ArchSpec arch_spec(int arch) {
+  ArchSpec A;
+  A.valid = 1;
+  A.fcn32 = (arch == FLM_ARCH_FCN32 || arch == FLM_ARCH_FCN32_VGG);
+  if (arch == FLM_ARCH_FCN8 || arch == FLM_ARCH_FCN32) {
+    // vanilla_encoder, networks/fcn.py:10-51: 5 x (pad 1, conv 3x3, BN, ReLU, pool); F = 64,128,256,256,256
+    const int f[6] = {3, 64, 128, 256, 256, 256};
+    A.n_enc = 5;
+    for (int i = 0; i < 5; ++i) {
+      A.enc[i] = EncLayer{f[i], f[i + 1], 1, 1};
+      A.f_idx[i] = i;
+    }
+  } else if (arch == FLM_ARCH_FCN8_VGG || arch == FLM_ARCH_FCN32_VGG) {
+    // get_vgg_encoder, networks/vgg16.py:27-72: conv 3x3 'same' + ReLU, pool closes each block
+    const int blocks[5] = {2, 2, 3, 3, 3};
+    const int ch[5] = {64, 128, 256, 512, 512};
+    int cin = 3, k = 0;
+    for (int bl = 0; bl < 5; ++bl)
+      for (int c = 0; c < blocks[bl]; ++c) {
+        A.enc[k] = EncLayer{cin, ch[bl], 0, c == blocks[bl] - 1};
+        if (c == blocks[bl] - 1) A.f_idx[bl] = k;
+        cin = ch[bl];
+        ++k;
+      }
+    A.n_enc = k;  // 13
+  } else {
+    A.valid = 0;
+    A.n_enc = 0;
+  }
+  return A;
+}
+
 static size_t take(size_t& cur, size_t bytes) {
   size_t o = cur;
   cur = align_up(cur + bytes, 256);
@@ -35,23 +67,28 @@ static ConvPack conv_pack(size_t& cur, int kh, int kw, int pad, int cin, int cou
   return c;
 }
 
-Fcn8Pack fcn8_pack_layout(int C, int dtype, int fcn32) {
+Fcn8Pack fcn8_pack_layout(int C, int dtype, int arch) {
   Fcn8Pack L;
   L.g = convt_geom(C, dtype);
   L.dtype = dtype;
-  L.fcn32 = fcn32;
+  L.arch = arch;
+  L.spec = arch_spec(arch);
+  const ArchSpec& A = L.spec;
+  const int fcn32 = A.fcn32;
   const int es = dtype == FLM_BF16 ? 2 : 4;
   size_t cur = 0;
   L.enc1_w = take(cur, sizeof(float) * 64 * 32);
   L.enc1_scale = take(cur, sizeof(float) * 64);
   L.enc1_shift = take(cur, sizeof(float) * 64);
-  for (int i = 0; i < 4; ++i) L.enc[i] = conv_pack(cur, 3, 3, 1, kEncF[i], kEncF[i + 1], kEncF[i + 1], es);
-  L.fc6 = conv_pack(cur, 7, 7, 3, kEncF[4], kFc, kFc, es);
+  for (int i = 1; i < A.n_enc; ++i)
+    L.enc[i] = conv_pack(cur, 3, 3, 1, A.enc[i].cin, A.enc[i].cout, align_up(A.enc[i].cout, 128), es);
+  const int c3 = A.enc[A.f_idx[2]].cout, c4 = A.enc[A.f_idx[3]].cout, c5 = A.enc[A.f_idx[4]].cout;
+  L.fc6 = conv_pack(cur, 7, 7, 3, c5, kFc, kFc, es);
   L.fc7 = conv_pack(cur, 1, 1, 0, kFc, kFc, kFc, es);
   // score convs write Cp channels (pad channels come out as exact zeros)
   L.score5 = conv_pack(cur, 1, 1, 0, kFc, L.g.Cp, 128, es);
-  L.score4 = conv_pack(cur, 1, 1, 0, kEncF[3], L.g.Cp, 128, es);
-  L.score3 = conv_pack(cur, 1, 1, 0, kEncF[2], L.g.Cp, 128, es);
+  L.score4 = conv_pack(cur, 1, 1, 0, c4, L.g.Cp, 128, es);
+  L.score3 = conv_pack(cur, 1, 1, 0, c3, L.g.Cp, 128, es);
   const size_t frag = (size_t)16 * L.g.G * L.g.MT * 64;  // 16 bytes per lane per (group, class tile)
   L.up5 = take(cur, fcn32 ? 0 : frag * 4);
   L.up4 = take(cur, fcn32 ? 0 : frag * 4);
@@ -158,24 +195,38 @@ static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c,
   return FLM_OK;
 }
 
-int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8Pack& L, char* blob) {
-  // enc1
-  if (!p.enc[0].kernel || !p.enc[0].bias || !p.enc[0].gamma) {
-    set_error("flm_fcn8_pack: enc1 parameters missing");
+int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pack& L, char* blob) {
+  const ArchSpec& A = L.spec;
+  if (!p.enc || p.n_enc != A.n_enc) {
+    set_error("flm_fcn_pack: this architecture has %d encoder convs, got %d", A.n_enc, p.n_enc);
     return FLM_ERR_ARG;
   }
-  pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(p.enc[0].kernel, (float*)(blob + L.enc1_w));
-  FLM_LAUNCH_CHECK("pack_enc1_kernel");
-  pack_affine_kernel<<<1, 64, 0, s>>>(p.enc[0], (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
-  FLM_LAUNCH_CHECK("pack_affine_kernel");
-  for (int i = 0; i < 4; ++i) {
-    if (!p.enc[i + 1].gamma || !p.enc[i + 1].beta || !p.enc[i + 1].mean || !p.enc[i + 1].var) {
-      set_error("flm_fcn8_pack: encoder level %d lacks BatchNormalization tensors", i + 2);
+  for (int i = 0; i < A.n_enc; ++i) {
+    const flm_conv_params& q = p.enc[i];
+    if (!q.kernel || !q.bias) {
+      set_error("flm_fcn_pack: encoder conv %d lacks kernel or bias", i + 1);
       return FLM_ERR_ARG;
     }
-    int rc = pack_conv(s, p.enc[i + 1], L.enc[i], blob, L.dtype);
+    if (A.enc[i].bn && (!q.gamma || !q.beta || !q.mean || !q.var)) {
+      set_error("flm_fcn_pack: encoder conv %d lacks BatchNormalization tensors", i + 1);
+      return FLM_ERR_ARG;
+    }
+  }
+  // first conv (3 input channels): its own kernel layout
+  {
+    flm_conv_params q = p.enc[0];
+    if (!A.enc[0].bn) q.gamma = q.beta = q.mean = q.var = nullptr;
+    pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(q.kernel, (float*)(blob + L.enc1_w));
+    FLM_LAUNCH_CHECK("pack_enc1_kernel");
+    pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+    FLM_LAUNCH_CHECK("pack_affine_kernel");
+  }
+  for (int i = 1; i < A.n_enc; ++i) {
+    flm_conv_params q = p.enc[i];
+    if (!A.enc[i].bn) q.gamma = q.beta = q.mean = q.var = nullptr;
+    int rc = pack_conv(s, q, L.enc[i], blob, L.dtype);
     if (rc) return rc;
-    pack_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>(p.enc[i + 1], (float*)(blob + L.enc[i].scale),
+    pack_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),
                                                                    (float*)(blob + L.enc[i].shift), L.enc[i].cout,
                                                                    L.enc[i].coutpad);
     FLM_LAUNCH_CHECK("pack_affine_kernel");
@@ -183,7 +234,7 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
   struct Item { const flm_conv_params* p; const ConvPack* c; int cout_real; };
   const Item items[5] = {{&p.fc6, &L.fc6, kFc}, {&p.fc7, &L.fc7, kFc}, {&p.score5, &L.score5, C},
                          {&p.score4, &L.score4, C}, {&p.score3, &L.score3, C}};
-  for (int ii = 0; ii < (L.fcn32 ? 3 : 5); ++ii) {
+  for (int ii = 0; ii < (A.fcn32 ? 3 : 5); ++ii) {
     const Item& it = items[ii];
     // Keras kernels of the score convs have C output columns; the packed rows C..coutpad-1 are zero.
     ConvPack c = *it.c;
@@ -196,7 +247,7 @@ int launch_pack_fcn8(hipStream_t s, const flm_fcn8_params& p, int C, const Fcn8P
                                                             it.cout_real, c.coutpad);
     FLM_LAUNCH_CHECK("pack_affine_kernel");
   }
-  if (L.fcn32) {  // fcn.py:145-146: one Conv2DTranspose(C, 64x64, stride 32), passed in the up3 slot
+  if (A.fcn32) {  // fcn.py:145-146: one Conv2DTranspose(C, 64x64, stride 32), passed in the up3 slot
     if (!p.up3) {
       set_error("flm_fcn32_pack: transposed-conv kernel missing");
       return FLM_ERR_ARG;

@@ -1,2 +1,2 @@
 from .basic_models import LANDMARKS_MODELS  # noqa: F401
-from .fcn import Fcn8Model, Fcn32Model, fcn_8, fcn_32  # noqa: F401
+from .fcn import Fcn8Model, Fcn32Model, Fcn8VggModel, Fcn32VggModel, fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg  # noqa: F401

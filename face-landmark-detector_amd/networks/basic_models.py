@@ -6,7 +6,7 @@ registry lists only ImageNet-backbone variants (whose constructors download weig
 broken 'default'; it has no entry for the vanilla FCN-8 the hot path is built on, so this
 registry adds 'fcn_8' and points 'default' at it.
 """
-from .fcn import fcn_8, fcn_32
+from .fcn import fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg
 
 
 def _not_built(name, why):
@@ -23,5 +23,6 @@ LANDMARKS_MODELS = {
     "default": fcn_8,
     "fcn_8_resnet50": _not_built("fcn_8_resnet50", _BACKBONE),
     "fcn_8_mobilenet": _not_built("fcn_8_mobilenet", _BACKBONE),
-    "fcn_8_vgg": _not_built("fcn_8_vgg", _BACKBONE),
+    "fcn_8_vgg": fcn_8_vgg,      # built without the ImageNet download (pretrained=None)
+    "fcn_32_vgg": fcn_32_vgg,
 }

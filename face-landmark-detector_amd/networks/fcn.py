@@ -28,8 +28,10 @@ def decode_mode_of(n_points: int):
 
 class Fcn8Model:
     model_name = "fcn_8"
-    _api = "fcn8"          # prefix of the C entry points (flm_fcn8_* / flm_fcn32_*)
-    _grid_growth = 8       # output grid = input + 8: (H/8 - 1)*8 + 16, fcn.py:121-124 has no final crop
+    _arch = _lib.ARCH_FCN8  # graph selector of the C entry points (enum flm_arch)
+    _grid_growth = 8        # output grid = input + 8: (H/8 - 1)*8 + 16, fcn.py:121-124 has no final crop
+    _fcn32 = False
+    _enc_layers = tuple(("enc%d" % i, True) for i in range(1, 6))   # (tensor prefix, has BatchNorm)
 
     def __init__(self, n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
         # defaults as networks/fcn.py:89-90; `dtype` selects the arithmetic of the conv stack:
@@ -53,7 +55,9 @@ class Fcn8Model:
         # the kernels address activations with 32-bit byte offsets: the largest tensor (f1, 64 channels at
         # half resolution) bounds the faces per launch; larger batches are processed in slices
         es = 4 if dtype == "f32" else 2
-        self.max_batch = max(1, (2 ** 32 - 1) // ((self.input_height // 2) * (self.input_width // 2) * 64 * es) - 1)
+        big = self.input_height * self.input_width * 64 if self._enc_layers is _VGG_LAYERS else \
+            (self.input_height // 2) * (self.input_width // 2) * 64
+        self.max_batch = max(1, (2 ** 32 - 1) // (big * es) - 1)
 
     # ---- weights ------------------------------------------------------------------------------
     def load_weights(self, path_or_params):
@@ -87,13 +91,16 @@ class Fcn8Model:
                 cp.var = up(name + "/moving_variance")
             return cp
 
-        p = _lib.Fcn8Params()
-        for i in range(5):
-            p.enc[i] = conv("enc%d" % (i + 1), True)
+        enc = (_lib.ConvParams * len(self._enc_layers))()
+        for i, (name, bn) in enumerate(self._enc_layers):
+            enc[i] = conv(name, bn)
+        p = _lib.FcnParams()
+        p.enc = enc
+        p.n_enc = len(self._enc_layers)
         p.fc6 = conv("fc6", False)
         p.fc7 = conv("fc7", False)
         p.score5 = conv("score5", False)
-        if self._api == "fcn8":
+        if not self._fcn32:
             p.score4 = conv("score4", False)
             p.score3 = conv("score3", False)
             p.up5 = up("up5/kernel")
@@ -101,12 +108,12 @@ class Fcn8Model:
             p.up3 = up("up3/kernel")
         else:  # fcn_32: the single 64x64 stride-32 transposed conv travels in the up3 slot
             p.up3 = up("up32/kernel")
-        nbytes = getattr(lib, "flm_%s_packed_bytes" % self._api)(self.n_classes, self._dt)
+        nbytes = lib.flm_fcn_packed_bytes(self._arch, self.n_classes, self._dt)
         if nbytes == 0:
             raise _lib.FlmError("n_classes=%d is outside what the kernels cover" % self.n_classes)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(getattr(lib, "flm_%s_pack" % self._api)(_lib.stream_ptr(), C.byref(p), self.n_classes, self._dt,
-                                                           _lib.ptr(packed), nbytes), "flm_%s_pack" % self._api)
+        _lib.check(lib.flm_fcn_pack(_lib.stream_ptr(), self._arch, C.byref(p), self.n_classes, self._dt,
+                                    _lib.ptr(packed), nbytes), "flm_fcn_pack")
         torch.cuda.current_stream().synchronize()  # the Keras-layout copies die with `held`
         self._packed = packed
 
@@ -117,8 +124,8 @@ class Fcn8Model:
         ws = self._ws.get(key)
         if ws is None:
             lib = _lib.load()
-            nbytes = getattr(lib, "flm_%s_workspace_bytes" % self._api)(n, self.input_height, self.input_width,
-                                                                        self.n_classes, self._dt, out_mode, dmode, npts)
+            nbytes = lib.flm_fcn_workspace_bytes(self._arch, n, self.input_height, self.input_width,
+                                                 self.n_classes, self._dt, out_mode, dmode, npts)
             if nbytes == 0:
                 raise _lib.FlmError("workspace query failed: %s" % lib.flm_last_error().decode())
             if len(self._ws) > 4:
@@ -176,10 +183,10 @@ class Fcn8Model:
                 self.forward_device(x[lo:hi], out, n_points, thresh, out_tensor[lo:hi])
             return out_tensor
         ws = self._workspace(n, om, dmode, npts)
-        _lib.check(getattr(lib, "flm_%s_forward" % self._api)(_lib.stream_ptr(), _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
+        _lib.check(lib.flm_fcn_forward(_lib.stream_ptr(), self._arch, _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
                                         self.input_height, self.input_width, c, self._dt, om, dmode, npts,
                                         float(thresh), _lib.ptr(out_tensor), _lib.ptr(ws), ws.numel()),
-                   "flm_fcn8_forward")
+                   "flm_fcn_forward")
         return out_tensor
 
     def intermediate(self, name, n, out="probs", n_points=0):
@@ -233,11 +240,47 @@ class Fcn32Model(Fcn8Model):
     output grid = input + 32.  Weight container: the fcn_8 tensors without score4/score3/up5/up4/up3,
     plus `up32/kernel` (64,64,C,C); `score5/*` is the 1x1 classifier the reference names "seg_feats"."""
     model_name = "fcn_32"
-    _api = "fcn32"
+    _arch = _lib.ARCH_FCN32
     _grid_growth = 32
+    _fcn32 = True
 
     def intermediate(self, name, n, out="probs", n_points=0):
         raise NotImplementedError("workspace views are exposed for fcn_8 only")
+
+
+_VGG_LAYERS = tuple(("block%d_conv%d" % (b, c), False)
+                    for b, k in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)) for c in range(1, k + 1))
+
+
+class Fcn8VggModel(Fcn8Model):
+    """fcn_8 on the VGG16 encoder (networks/fcn.py:153-157, networks/vgg16.py:17-81), built WITHOUT the
+    ImageNet download the reference performs by default (`pretrained=None`): 13 conv3x3+ReLU layers
+    (tensors `block{b}_conv{c}/kernel|bias`, the Keras layer names), f3/f4/f5 with 256/512/512 channels,
+    then the same head."""
+    model_name = "fcn_8_vgg"
+    _arch = _lib.ARCH_FCN8_VGG
+    _enc_layers = _VGG_LAYERS
+
+    def intermediate(self, name, n, out="probs", n_points=0):
+        raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")
+
+
+class Fcn32VggModel(Fcn8VggModel):
+    model_name = "fcn_32_vgg"
+    _arch = _lib.ARCH_FCN32_VGG
+    _grid_growth = 32
+    _fcn32 = True
+
+
+def fcn_8_vgg(n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
+    """networks/fcn.py:153-157."""
+    return Fcn8VggModel(n_classes, input_height=input_height, input_width=input_width, channels=channels, dtype=dtype)
+
+
+def fcn_32_vgg(n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
+    """networks/fcn.py:160-164."""
+    return Fcn32VggModel(n_classes, input_height=input_height, input_width=input_width, channels=channels,
+                         dtype=dtype)
 
 
 def fcn_32(n_classes, encoder=None, input_height=416, input_width=608, channels=3, dtype="f32"):

@@ -23,6 +23,62 @@ ENC_FILTERS = (64, 128, 256, 256, 256)  # networks/fcn.py:13,34,43
 FC_WIDTH = 4096                          # networks/fcn.py:98,100
 
 
+VGG_BLOCKS = ((1, 2, 64), (2, 2, 128), (3, 3, 256), (4, 3, 512), (5, 3, 512))  # networks/vgg16.py:27-72
+
+
+def vgg_param_shapes(n_classes: int, channels: int = 3, fcn32: bool = False) -> dict:
+    """fcn_8_vgg / fcn_32_vgg: 13 conv3x3 (Keras names block{b}_conv{c}), head on 512-channel f5/f4, 256-channel f3."""
+    shapes = {}
+    cin = channels
+    for b, k, f in VGG_BLOCKS:
+        for c in range(1, k + 1):
+            shapes["block%d_conv%d/kernel" % (b, c)] = (3, 3, cin, f)
+            shapes["block%d_conv%d/bias" % (b, c)] = (f,)
+            cin = f
+    shapes["fc6/kernel"] = (7, 7, 512, FC_WIDTH)
+    shapes["fc6/bias"] = (FC_WIDTH,)
+    shapes["fc7/kernel"] = (1, 1, FC_WIDTH, FC_WIDTH)
+    shapes["fc7/bias"] = (FC_WIDTH,)
+    shapes["score5/kernel"] = (1, 1, FC_WIDTH, n_classes)
+    shapes["score5/bias"] = (n_classes,)
+    if fcn32:
+        shapes["up32/kernel"] = (64, 64, n_classes, n_classes)
+        return shapes
+    shapes["score4/kernel"] = (1, 1, 512, n_classes)
+    shapes["score4/bias"] = (n_classes,)
+    shapes["score3/kernel"] = (1, 1, 256, n_classes)
+    shapes["score3/bias"] = (n_classes,)
+    shapes["up5/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up4/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up3/kernel"] = (16, 16, n_classes, n_classes)
+    return shapes
+
+
+def synth_vgg_weights(n_classes: int = 68, seed: int = 2, channels: int = 3, fcn32: bool = False) -> dict:
+    """Seeded synthetic parameters for the VGG variants (he_normal kernels, small biases; see synth_fcn8_weights)."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shp in vgg_param_shapes(n_classes, channels, fcn32).items():
+        layer, tensor = name.split("/")
+        if tensor == "bias":
+            p[name] = rng.standard_normal(shp, dtype=np.float32) * np.float32(0.01)
+            continue
+        if layer.startswith("up"):
+            kh, kw, co, ci = shp
+            stride = {"up3": 8, "up32": 32}.get(layer, 2)
+            std = np.sqrt(1.0 / ((kh // stride) * (kw // stride) * ci))
+        else:
+            kh, kw, ci, co = shp
+            std = np.sqrt(2.0 / (kh * kw * ci))
+        w = rng.standard_normal(shp, dtype=np.float32) * np.float32(std)
+        if layer == "block1_conv1":
+            w *= np.float32(1.0 / 64.0)   # mean-subtracted byte inputs
+        if layer.startswith("score"):
+            w *= np.float32(0.125)
+        p[name] = w
+    return p
+
+
 def fcn32_param_shapes(n_classes: int, channels: int = 3) -> dict:
     """fcn_32 (networks/fcn.py:129-150): encoder + fc6 + fc7 + 1x1 classifier + one 64x64/s32 transposed conv."""
     s8 = fcn8_param_shapes(n_classes, channels)
@@ -123,7 +179,10 @@ def load_weights_file(path: str) -> dict:
 
 
 def check_params(params: dict, n_classes: int, channels: int = 3, arch: str = "fcn_8") -> None:
-    want = fcn32_param_shapes(n_classes, channels) if arch == "fcn_32" else fcn8_param_shapes(n_classes, channels)
+    want = {"fcn_32": lambda: fcn32_param_shapes(n_classes, channels),
+            "fcn_8_vgg": lambda: vgg_param_shapes(n_classes, channels, False),
+            "fcn_32_vgg": lambda: vgg_param_shapes(n_classes, channels, True)}.get(
+                arch, lambda: fcn8_param_shapes(n_classes, channels))()
     missing = sorted(set(want) - set(params))
     if missing:
         raise KeyError("weight container lacks tensors: %s" % ", ".join(missing))

@@ -142,6 +142,28 @@ int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x
                       int n_points, float thresh, void* out_dev, void* workspace_dev,
                       size_t workspace_bytes);
 
+/* ---- architecture-generic entry points ------------------------------------------------------------
+ * The registry of the reference (networks/basic_models.py:59-64, networks/fcn.py:153-192) builds the same
+ * FCN head on several encoders.  `arch` selects the graph; the flm_fcn8_* / flm_fcn32_* calls above are
+ * these with arch = FLM_ARCH_FCN8 / FLM_ARCH_FCN32.  Encoder convs arrive in network order in `enc`:
+ * 5 layers for the vanilla encoder (BatchNorm tensors required), 13 for VGG16 (block1_conv1 ..
+ * block5_conv3, networks/vgg16.py:27-72, no BatchNorm: gamma..var NULL). */
+enum flm_arch { FLM_ARCH_FCN8 = 0, FLM_ARCH_FCN32 = 1, FLM_ARCH_FCN8_VGG = 2, FLM_ARCH_FCN32_VGG = 3 };
+typedef struct flm_fcn_params {
+  const flm_conv_params* enc; /* host array of n_enc entries (the pointers inside are device pointers) */
+  int n_enc;
+  flm_conv_params fc6, fc7, score5, score4, score3;
+  const float *up5, *up4, *up3; /* FCN-32 variants: only up3 = the (64,64,C,C) kernel */
+} flm_fcn_params;
+size_t flm_fcn_packed_bytes(int arch, int n_classes, int dtype);
+int flm_fcn_pack(flm_stream_t stream, int arch, const flm_fcn_params* params, int n_classes, int dtype,
+                 void* packed_dev, size_t packed_bytes);
+size_t flm_fcn_workspace_bytes(int arch, int n, int h, int w, int n_classes, int dtype, int out_mode,
+                               int decode_mode, int n_points);
+int flm_fcn_forward(flm_stream_t stream, int arch, const void* packed_dev, const void* x_dev, int in_format,
+                    int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                    int n_points, float thresh, void* out_dev, void* workspace_dev, size_t workspace_bytes);
+
 /* One named Conv2D layer of the model in isolation ("enc2".."enc5" with BN+ReLU+pool fused,
  * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  Used by
  * the layer parity tests and by bench.py to time the dominant kernel on its own stream. */

@@ -84,6 +84,19 @@ def vanilla_encoder_ref(x_nchw, p, dtype):
     return levels
 
 
+def vgg_encoder_ref(x_nchw, p, dtype):
+    """networks/vgg16.py:27-72 (pretrained=None): blocks of Conv2D(3x3, 'same', relu) closed by MaxPooling2D(2,2)."""
+    levels = []
+    x = x_nchw
+    for b, k in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)):
+        for c in range(1, k + 1):
+            n = "block%d_conv%d" % (b, c)
+            x = torch.relu(_conv(x, p[n + "/kernel"], p[n + "/bias"], 1, dtype))
+        x = F.max_pool2d(x, 2, 2)
+        levels.append(x)
+    return levels
+
+
 def crop_ref(o1, o2):
     """networks/fcn.py:55-86.  The larger map loses its RIGHT columns and BOTTOM rows
     (Cropping2D(((0,0),(0,cx))) then Cropping2D(((0,cy),(0,0)))): the top-left window stays."""
@@ -101,10 +114,11 @@ def crop_ref(o1, o2):
     return o1, o2
 
 
-def fcn8_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, return_intermediates=False):
-    """networks/fcn.py:89-122 up to (not including) the softmax.  x: [N,H,W,3] preprocessed."""
+def fcn8_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, return_intermediates=False, encoder="vanilla"):
+    """networks/fcn.py:89-122 up to (not including) the softmax.  x: [N,H,W,3] preprocessed.
+    encoder="vgg" is fcn_8_vgg (fcn.py:153-157)."""
     x = _t(x_nhwc, dtype).permute(0, 3, 1, 2).contiguous()
-    f1, f2, f3, f4, f5 = vanilla_encoder_ref(x, p, dtype)
+    f1, f2, f3, f4, f5 = (vgg_encoder_ref if encoder == "vgg" else vanilla_encoder_ref)(x, p, dtype)
     o = torch.relu(_conv(f5, p["fc6/kernel"], p["fc6/bias"], 3, dtype))   # fcn.py:98 7x7 'same'; :99 dropout = id
     fc6 = o
     o = torch.relu(_conv(o, p["fc7/kernel"], p["fc7/bias"], 0, dtype))    # fcn.py:100-101
@@ -129,11 +143,11 @@ def fcn8_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, return_int
     return logits.numpy()
 
 
-def fcn32_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
+def fcn32_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, encoder="vanilla") -> np.ndarray:
     """networks/fcn.py:129-146 up to the softmax: encoder, fc6, fc7, 1x1 classifier ("seg_feats", :143-144),
     Conv2DTranspose(C, 64x64, stride 32, no bias) (:145-146).  Output grid (H/32 - 1)*32 + 64 = H + 32."""
     x = _t(x_nhwc, dtype).permute(0, 3, 1, 2).contiguous()
-    f5 = vanilla_encoder_ref(x, p, dtype)[4]
+    f5 = (vgg_encoder_ref if encoder == "vgg" else vanilla_encoder_ref)(x, p, dtype)[4]
     o = torch.relu(_conv(f5, p["fc6/kernel"], p["fc6/bias"], 3, dtype))   # fcn.py:138
     o = torch.relu(_conv(o, p["fc7/kernel"], p["fc7/bias"], 0, dtype))    # fcn.py:140
     o = _conv(o, p["score5/kernel"], p["score5/bias"], 0, dtype)          # fcn.py:143-144
@@ -141,18 +155,18 @@ def fcn32_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.nda
     return o.permute(0, 2, 3, 1).contiguous().numpy()
 
 
-def fcn32_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
+def fcn32_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, encoder="vanilla") -> np.ndarray:
     """fcn_32 + get_segmentation_model (networks/utils.py:22-31): [N, H'*W', C] probabilities."""
-    logits = torch.from_numpy(fcn32_logits_ref(x_nhwc, p, dtype))
+    logits = torch.from_numpy(fcn32_logits_ref(x_nhwc, p, dtype, encoder))
     n, h, w, c = logits.shape
     return torch.softmax(logits.reshape(n, h * w, c), dim=-1).numpy()
 
 
-def fcn8_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32) -> np.ndarray:
+def fcn8_predict_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, encoder="vanilla") -> np.ndarray:
     """`model.predict` of the model built by fcn_8 + get_segmentation_model
     (networks/utils.py:22-31): Reshape((H'*W', C)) then softmax over the last axis.
     Returns [N, H'*W', C]."""
-    logits = torch.from_numpy(fcn8_logits_ref(x_nhwc, p, dtype))
+    logits = torch.from_numpy(fcn8_logits_ref(x_nhwc, p, dtype, encoder=encoder))
     n, h, w, c = logits.shape
     pr = torch.softmax(logits.reshape(n, h * w, c), dim=-1)
     return pr.numpy()

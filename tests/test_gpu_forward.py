@@ -193,3 +193,24 @@ def test_fcn32_forward(flm, weights68):
         got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
         assert got.shape == exp.shape == (n, (h + 32) * (w + 32), c)
         assert np.abs(got - exp).max() <= 1e-5, (n, h, w, c, np.abs(got - exp).max())
+
+
+def test_vgg_variants(flm):
+    """fcn_8_vgg / fcn_32_vgg (networks/fcn.py:153-164 on networks/vgg16.py:17-81, no pretrained download):
+    13 conv3x3+ReLU encoder layers, 512-channel f4/f5, same head and decoders."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_vgg_weights
+    from oracle import fcn_ref
+    rng = np.random.default_rng(33)
+    for name, fcn32, (n, h, w, c) in (("fcn_8_vgg", False, (2, 64, 96, 68)), ("fcn_32_vgg", True, (1, 64, 64, 68)),
+                                      ("fcn_8_vgg", False, (1, 32, 32, 5))):
+        params = synth_vgg_weights(c, seed=4, fcn32=fcn32)
+        model = LANDMARKS_MODELS[name](c, input_height=h, input_width=w)
+        model.load_weights(params)
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in img])
+        ref = fcn_ref.fcn32_predict_ref if fcn32 else fcn_ref.fcn8_predict_ref
+        exp = ref(x_ref, params, encoder="vgg")
+        got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
+        assert got.shape == exp.shape
+        assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
