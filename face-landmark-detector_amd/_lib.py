@@ -51,7 +51,7 @@ class FcnParams(C.Structure):
                 ("up5", C.c_void_p), ("up4", C.c_void_p), ("up3", C.c_void_p)]
 
 
-ARCH_FCN8, ARCH_FCN32, ARCH_FCN8_VGG, ARCH_FCN32_VGG = 0, 1, 2, 3
+ARCH_FCN8, ARCH_FCN32, ARCH_FCN8_VGG, ARCH_FCN32_VGG, ARCH_FCN8_MOBILENET, ARCH_FCN32_MOBILENET = 0, 1, 2, 3, 4, 5
 
 _lib = None
 

@@ -26,6 +26,7 @@ SOURCES = [
     "flm_convt.hip",
     "flm_decode.hip",
     "flm_misc.hip",
+    "flm_mobile.hip",
 ]
 # -ffp-contract=off: only the fma() calls written in the sources fuse, so the arithmetic of the
 # warp / decode kernels is exactly what their comments (and oracle/) state.

@@ -61,7 +61,7 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   size_t cur = 0;
   int hh = h, ww = w;
   for (int i = 0; i < A.n_enc; ++i) {
-    if (A.enc[i].pool) {
+    if (A.enc[i].pool || A.enc[i].stride == 2) {
       hh >>= 1;
       ww >>= 1;
     }
@@ -328,20 +328,40 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   float* seg = reinterpret_cast<float*>(ws + W.seg);
 
   // encoder: vanilla (networks/fcn.py:10-51) or VGG16 (networks/vgg16.py:27-72)
-  static const char* const enc_names[kMaxEnc] = {"enc1", "enc2", "enc3", "enc4", "enc5", "enc6", "enc7",
-                                                 "enc8", "enc9", "enc10", "enc11", "enc12", "enc13"};
+  static const char* const enc_names[kMaxEnc] = {
+      "enc1",  "enc2",  "enc3",  "enc4",  "enc5",  "enc6",  "enc7",  "enc8",  "enc9",  "enc10", "enc11", "enc12", "enc13", "enc14",
+      "enc15", "enc16", "enc17", "enc18", "enc19", "enc20", "enc21", "enc22", "enc23", "enc24", "enc25", "enc26", "enc27"};
+  const bool mobilenet = A.enc[0].kind == ENC_MB_CONV1;
+  if (mobilenet && bf) {
+    set_error("flm_fcn_forward: the MobileNet encoder is built in fp32 only");
+    return FLM_ERR_UNSUPPORTED;
+  }
   { ProfScope ps(s, enc_names[0]);
-  rc = launch_enc1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
-                   reinterpret_cast<const float*>(blob + L.enc1_scale),
-                   reinterpret_cast<const float*>(blob + L.enc1_shift), ws + W.act[0], bf, A.enc[0].pool); }
+  if (mobilenet)
+    rc = launch_mb_conv1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
+                         reinterpret_cast<const float*>(blob + L.enc1_scale),
+                         reinterpret_cast<const float*>(blob + L.enc1_shift), reinterpret_cast<float*>(ws + W.act[0]));
+  else
+    rc = launch_enc1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
+                     reinterpret_cast<const float*>(blob + L.enc1_scale),
+                     reinterpret_cast<const float*>(blob + L.enc1_shift), ws + W.act[0], bf, A.enc[0].pool); }
   if (rc) return rc;
-  int hh = A.enc[0].pool ? h / 2 : h, ww = A.enc[0].pool ? w / 2 : w;
+  const bool half0 = A.enc[0].pool || A.enc[0].stride == 2;
+  int hh = half0 ? h / 2 : h, ww = half0 ? w / 2 : w;
   for (int i = 1; i < A.n_enc; ++i) {
+    const EncLayer& e = A.enc[i];
     { ProfScope ps(s, enc_names[i]);
-    rc = conv_layer(s, blob, L.enc[i], ws + W.act[i - 1], ws + W.act[i], n, hh, ww, /*relu*/ 1, A.enc[i].pool, 0,
-                    dtype); }
+    if (e.kind == ENC_MB_DW)
+      rc = launch_mb_depthwise(s, reinterpret_cast<const float*>(ws + W.act[i - 1]), n, hh, ww, e.cin, e.stride,
+                               reinterpret_cast<const float*>(blob + L.enc[i].w),
+                               reinterpret_cast<const float*>(blob + L.enc[i].scale),
+                               reinterpret_cast<const float*>(blob + L.enc[i].shift),
+                               reinterpret_cast<float*>(ws + W.act[i]));
+    else
+      rc = conv_layer(s, blob, L.enc[i], ws + W.act[i - 1], ws + W.act[i], n, hh, ww,
+                      /*relu*/ e.kind == ENC_MB_PW ? 2 : 1, e.pool, 0, dtype); }
     if (rc) return rc;
-    if (A.enc[i].pool) {
+    if (e.pool || e.stride == 2) {
       hh /= 2;
       ww /= 2;
     }

@@ -32,11 +32,19 @@ constexpr float kBnEps = 1e-3f;  // keras BatchNormalization default epsilon
 // ---- architecture constants (networks/fcn.py:13,34,43,98,100) ------------------------------
 constexpr int kFc = 4096;
 constexpr int kMaxClasses = 96;
-constexpr int kMaxEnc = 13;
+constexpr int kMaxEnc = 27;
 
-// Encoder description: every layer is Conv2D 3x3 'same' + (BatchNorm) + ReLU (+ MaxPool 2x2).
+// Encoder description.
+enum EncKind {
+  ENC_FIRST3 = 0,  // 3-channel Conv2D 3x3 'same' + (BN) + ReLU (+ MaxPool 2x2): enc1_kernel
+  ENC_CONV3 = 1,   // Conv2D 3x3 'same' + (BN) + ReLU (+ MaxPool 2x2): igemm_kernel
+  ENC_MB_CONV1 = 2,  // MobileNet conv1: pad 1, 3x3 stride 2, no bias, BN, ReLU6 (3 -> 32)
+  ENC_MB_DW = 3,     // MobileNet depthwise 3x3 (stride 1|2), no bias, BN, ReLU6
+  ENC_MB_PW = 4      // MobileNet pointwise 1x1, no bias, BN, ReLU6: igemm_kernel
+};
 struct EncLayer {
   int cin, cout, bn, pool;
+  int kind, stride;
 };
 struct ArchSpec {
   int n_enc;
@@ -45,7 +53,8 @@ struct ArchSpec {
   int fcn32;     // one 64x64 stride-32 transposed conv instead of the FCN-8 skip decoder
   int valid;
 };
-// FLM_ARCH_FCN8 / FCN32: vanilla_encoder (networks/fcn.py:10-51); *_VGG: get_vgg_encoder (networks/vgg16.py:17-81)
+// FLM_ARCH_FCN8 / FCN32: vanilla_encoder (networks/fcn.py:10-51); *_VGG: get_vgg_encoder (networks/vgg16.py:17-81);
+// *_MOBILENET: get_mobilenet_encoder (networks/mobilenet.py:59-114)
 ArchSpec arch_spec(int arch);
 
 // Geometry of the transposed-conv kernels for a class count C.
@@ -114,7 +123,7 @@ struct IgemmDesc {
   int coutpad;  // rows of wt (multiple of 128)
   int ldc;      // channel stride of y
   int kh, kw, pad;
-  int relu, pool, posmajor;
+  int relu, pool, posmajor;  // relu: 0 none, 1 ReLU, 2 ReLU6
   float* splitk_ws;        // optional scratch for split-K partial sums (null: never split)
   size_t splitk_ws_bytes;
 };
@@ -134,6 +143,11 @@ struct ConvTDesc {
   ConvTGeom g;
 };
 int launch_convt(hipStream_t s, const ConvTDesc& d);
+
+int launch_mb_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
+                    const float* scale, const float* shift, float* y);
+int launch_mb_depthwise(hipStream_t s, const float* x, int n, int h, int w, int c, int stride, const float* wgt,
+                        const float* scale, const float* shift, float* y);
 
 size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points);
 int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,

@@ -43,6 +43,7 @@ struct IgemmArgs {
   const float* shift;
   void* y;             // operand type, or fp32 when out_f32
   int out_f32;
+  float relu_max;      // upper clamp applied with the ReLU (6 for ReLU6, +inf otherwise)
   int n, h, w, cin;
   int cout, ldc;
   int kh, kw, pad;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float u = fmaf(acc[i][j][4 * g + e], sc, sh);
-            if (RELU) u = fmaxf(u, 0.f);
+            if (RELU) u = fminf(fmaxf(u, 0.f), a.relu_max);
             v = fmaxf(v, u);
           }
           const int m = mbase + 8 * g + 4 * lh;  // first row of the quad
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float u = fmaf(acc[i][j][r], sc, sh);
-          if (RELU) u = fmaxf(u, 0.f);
+          if (RELU) u = fminf(fmaxf(u, 0.f), a.relu_max);
           if (a.ksplit > 1) {
             if (cok && m < a.M) a.part[((size_t)blockIdx.y * a.M + m) * a.ldc + col] = acc[i][j][r];
             continue;
@@ -496,6 +497,7 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   IgemmArgs a;
   a.x = d.x; a.wt = d.wt; a.scale = d.scale; a.shift = d.shift; a.y = d.y;
   a.out_f32 = d.bf16 ? d.out_f32 : 1;
+  a.relu_max = d.relu == 2 ? 6.0f : 3.402823466e38f;
   a.n = d.n; a.h = d.h; a.w = d.w; a.cin = d.cin; a.cout = d.cout; a.ldc = d.ldc;
   a.kh = d.kh; a.kw = d.kw; a.pad = d.pad;
   a.M = (int)M;

@@ -23,13 +23,13 @@ ConvTGeom convt_geom(int C, int dtype) {
 ArchSpec arch_spec(int arch) {
   ArchSpec A;
   A.valid = 1;
-  A.fcn32 = (arch == FLM_ARCH_FCN32 || arch == FLM_ARCH_FCN32_VGG);
+  A.fcn32 = (arch == FLM_ARCH_FCN32 || arch == FLM_ARCH_FCN32_VGG || arch == FLM_ARCH_FCN32_MOBILENET);
   if (arch == FLM_ARCH_FCN8 || arch == FLM_ARCH_FCN32) {
     // vanilla_encoder, networks/fcn.py:10-51: 5 x (pad 1, conv 3x3, BN, ReLU, pool); F = 64,128,256,256,256
     const int f[6] = {3, 64, 128, 256, 256, 256};
     A.n_enc = 5;
     for (int i = 0; i < 5; ++i) {
-      A.enc[i] = EncLayer{f[i], f[i + 1], 1, 1};
+      A.enc[i] = EncLayer{f[i], f[i + 1], 1, 1, i == 0 ? ENC_FIRST3 : ENC_CONV3, 1};
       A.f_idx[i] = i;
     }
   } else if (arch == FLM_ARCH_FCN8_VGG || arch == FLM_ARCH_FCN32_VGG) {
@@ -39,12 +39,27 @@ ArchSpec arch_spec(int arch) {
     int cin = 3, k = 0;
     for (int bl = 0; bl < 5; ++bl)
       for (int c = 0; c < blocks[bl]; ++c) {
-        A.enc[k] = EncLayer{cin, ch[bl], 0, c == blocks[bl] - 1};
+        A.enc[k] = EncLayer{cin, ch[bl], 0, c == blocks[bl] - 1, k == 0 ? ENC_FIRST3 : ENC_CONV3, 1};
         if (c == blocks[bl] - 1) A.f_idx[bl] = k;
         cin = ch[bl];
         ++k;
       }
     A.n_enc = k;  // 13
+  } else if (arch == FLM_ARCH_FCN8_MOBILENET || arch == FLM_ARCH_FCN32_MOBILENET) {
+    // get_mobilenet_encoder, networks/mobilenet.py:79-102: conv1 (stride 2), then 13 depthwise-separable blocks;
+    // strides 2 at blocks 2, 4, 6, 12; f1..f5 = outputs of blocks 1, 3, 5, 11, 13
+    const int pw[13] = {64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 1024};
+    const int st[13] = {1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1, 2, 1};
+    int k = 0, cin = 32;
+    A.enc[k++] = EncLayer{3, 32, 1, 0, ENC_MB_CONV1, 2};
+    for (int b = 0; b < 13; ++b) {
+      A.enc[k++] = EncLayer{cin, cin, 1, 0, ENC_MB_DW, st[b]};
+      A.enc[k++] = EncLayer{cin, pw[b], 1, 0, ENC_MB_PW, 1};
+      cin = pw[b];
+    }
+    A.n_enc = k;  // 27
+    const int fb[5] = {1, 3, 5, 11, 13};
+    for (int i = 0; i < 5; ++i) A.f_idx[i] = 2 * fb[i];  // index of conv_pw_<block>
   } else {
     A.valid = 0;
     A.n_enc = 0;
@@ -80,8 +95,21 @@ Fcn8Pack fcn8_pack_layout(int C, int dtype, int arch) {
   L.enc1_w = take(cur, sizeof(float) * 64 * 32);
   L.enc1_scale = take(cur, sizeof(float) * 64);
   L.enc1_shift = take(cur, sizeof(float) * 64);
-  for (int i = 1; i < A.n_enc; ++i)
-    L.enc[i] = conv_pack(cur, 3, 3, 1, A.enc[i].cin, A.enc[i].cout, align_up(A.enc[i].cout, 128), es);
+  for (int i = 1; i < A.n_enc; ++i) {
+    const EncLayer& e = A.enc[i];
+    if (e.kind == ENC_MB_DW) {  // [9][C] filter + scale/shift, fp32
+      ConvPack c;
+      c.kh = c.kw = 3; c.pad = 1; c.cin = c.cout = c.coutpad = e.cin;
+      c.w = take(cur, sizeof(float) * 9 * e.cin);
+      c.scale = take(cur, sizeof(float) * e.cin);
+      c.shift = take(cur, sizeof(float) * e.cin);
+      L.enc[i] = c;
+    } else if (e.kind == ENC_MB_PW) {
+      L.enc[i] = conv_pack(cur, 1, 1, 0, e.cin, e.cout, (int)align_up(e.cout, 128), es);
+    } else {
+      L.enc[i] = conv_pack(cur, 3, 3, 1, e.cin, e.cout, (int)align_up(e.cout, 128), es);
+    }
+  }
   const int c3 = A.enc[A.f_idx[2]].cout, c4 = A.enc[A.f_idx[3]].cout, c5 = A.enc[A.f_idx[4]].cout;
   L.fc6 = conv_pack(cur, 7, 7, 3, c5, kFc, kFc, es);
   L.fc7 = conv_pack(cur, 1, 1, 0, kFc, kFc, kFc, es);
@@ -179,8 +207,8 @@ __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__
 }
 
 static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c, char* blob, int dtype) {
-  if (!p.kernel || !p.bias) {
-    set_error("flm_fcn8_pack: conv layer lacks kernel or bias");
+  if (!p.kernel) {
+    set_error("flm_fcn_pack: conv layer lacks its kernel");
     return FLM_ERR_ARG;
   }
   const size_t total = (size_t)c.coutpad * c.kh * c.kw * c.cin;
@@ -203,7 +231,8 @@ int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pac
   }
   for (int i = 0; i < A.n_enc; ++i) {
     const flm_conv_params& q = p.enc[i];
-    if (!q.kernel || !q.bias) {
+    const bool needs_bias = A.enc[i].kind == ENC_FIRST3 || A.enc[i].kind == ENC_CONV3;
+    if (!q.kernel || (needs_bias && !q.bias)) {
       set_error("flm_fcn_pack: encoder conv %d lacks kernel or bias", i + 1);
       return FLM_ERR_ARG;
     }
@@ -216,14 +245,28 @@ int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pac
   {
     flm_conv_params q = p.enc[0];
     if (!A.enc[0].bn) q.gamma = q.beta = q.mean = q.var = nullptr;
-    pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(q.kernel, (float*)(blob + L.enc1_w));
-    FLM_LAUNCH_CHECK("pack_enc1_kernel");
-    pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+    if (A.enc[0].kind == ENC_MB_CONV1) {  // Keras (3,3,3,32) is already [27][32]
+      FLM_HIP(hipMemcpyAsync(blob + L.enc1_w, q.kernel, sizeof(float) * 27 * 32, hipMemcpyDeviceToDevice, s));
+      pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 32, 32);
+    } else {
+      pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(q.kernel, (float*)(blob + L.enc1_w));
+      FLM_LAUNCH_CHECK("pack_enc1_kernel");
+      pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+    }
     FLM_LAUNCH_CHECK("pack_affine_kernel");
   }
   for (int i = 1; i < A.n_enc; ++i) {
     flm_conv_params q = p.enc[i];
     if (!A.enc[i].bn) q.gamma = q.beta = q.mean = q.var = nullptr;
+    if (A.enc[i].kind == ENC_MB_DW) {  // Keras depthwise kernel (3,3,C,1) is already [9][C]
+      FLM_HIP(hipMemcpyAsync(blob + L.enc[i].w, q.kernel, sizeof(float) * 9 * A.enc[i].cin,
+                             hipMemcpyDeviceToDevice, s));
+      pack_affine_kernel<<<cdiv(A.enc[i].cin, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),
+                                                                 (float*)(blob + L.enc[i].shift), A.enc[i].cin,
+                                                                 A.enc[i].cin);
+      FLM_LAUNCH_CHECK("pack_affine_kernel");
+      continue;
+    }
     int rc = pack_conv(s, q, L.enc[i], blob, L.dtype);
     if (rc) return rc;
     pack_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),

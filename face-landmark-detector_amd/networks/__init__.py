@@ -1,2 +1,3 @@
 from .basic_models import LANDMARKS_MODELS  # noqa: F401
-from .fcn import Fcn8Model, Fcn32Model, Fcn8VggModel, Fcn32VggModel, fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg  # noqa: F401
+from .fcn import (Fcn8Model, Fcn32Model, Fcn8VggModel, Fcn32VggModel, Fcn8MobilenetModel, Fcn32MobilenetModel,  # noqa: F401
+                  fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg, fcn_8_mobilenet, fcn_32_mobilenet)

@@ -6,7 +6,7 @@ registry lists only ImageNet-backbone variants (whose constructors download weig
 broken 'default'; it has no entry for the vanilla FCN-8 the hot path is built on, so this
 registry adds 'fcn_8' and points 'default' at it.
 """
-from .fcn import fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg
+from .fcn import fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg, fcn_8_mobilenet, fcn_32_mobilenet
 
 
 def _not_built(name, why):
@@ -15,14 +15,15 @@ def _not_built(name, why):
     return ctor
 
 
-_BACKBONE = "its encoder fetches ImageNet weights at construction (no network); SURVEY.md section 8 row F4"
+_BACKBONE = "residual bottleneck blocks (strided convs, 3x3 s2 max-pool, adds) are not built; SURVEY.md section 8 row F4"
 
 LANDMARKS_MODELS = {
     "fcn_8": fcn_8,
     "fcn_32": fcn_32,
     "default": fcn_8,
     "fcn_8_resnet50": _not_built("fcn_8_resnet50", _BACKBONE),
-    "fcn_8_mobilenet": _not_built("fcn_8_mobilenet", _BACKBONE),
+    "fcn_8_mobilenet": fcn_8_mobilenet,   # likewise, fp32
+    "fcn_32_mobilenet": fcn_32_mobilenet,
     "fcn_8_vgg": fcn_8_vgg,      # built without the ImageNet download (pretrained=None)
     "fcn_32_vgg": fcn_32_vgg,
 }

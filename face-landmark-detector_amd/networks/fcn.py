@@ -81,14 +81,18 @@ class Fcn8Model:
             return t.data_ptr()
 
         def conv(name, bn):
+            """bn: False, True (BN tensors under the conv's own prefix) or a separate BN layer prefix."""
             cp = _lib.ConvParams()
-            cp.kernel = up(name + "/kernel")
-            cp.bias = up(name + "/bias")
+            kname = name + ("/depthwise_kernel" if name + "/depthwise_kernel" in params else "/kernel")
+            cp.kernel = up(kname)
+            if name + "/bias" in params:
+                cp.bias = up(name + "/bias")
             if bn:
-                cp.gamma = up(name + "/gamma")
-                cp.beta = up(name + "/beta")
-                cp.mean = up(name + "/moving_mean")
-                cp.var = up(name + "/moving_variance")
+                b = name if bn is True else bn
+                cp.gamma = up(b + "/gamma")
+                cp.beta = up(b + "/beta")
+                cp.mean = up(b + "/moving_mean")
+                cp.var = up(b + "/moving_variance")
             return cp
 
         enc = (_lib.ConvParams * len(self._enc_layers))()
@@ -281,6 +285,47 @@ def fcn_32_vgg(n_classes, input_height=416, input_width=608, channels=3, dtype="
     """networks/fcn.py:160-164."""
     return Fcn32VggModel(n_classes, input_height=input_height, input_width=input_width, channels=channels,
                          dtype=dtype)
+
+
+_MOBILENET_LAYERS = (("conv1", "conv1_bn"),) + tuple(
+    x for i in range(1, 14) for x in (("conv_dw_%d" % i, "conv_dw_%d_bn" % i), ("conv_pw_%d" % i, "conv_pw_%d_bn" % i)))
+
+
+class Fcn8MobilenetModel(Fcn8Model):
+    """fcn_8 on the MobileNet-v1 encoder (networks/fcn.py:181-185, networks/mobilenet.py:59-114; alpha 1),
+    built without the ImageNet download.  Tensors carry the Keras layer names: `conv1/kernel`,
+    `conv_dw_i/depthwise_kernel` (3,3,C,1), `conv_pw_i/kernel`, and `<layer>_bn/gamma|beta|moving_mean|
+    moving_variance`; no biases.  f3/f4/f5 have 256/512/1024 channels.  fp32 only."""
+    model_name = "fcn_8_mobilenet"
+    _arch = _lib.ARCH_FCN8_MOBILENET
+    _enc_layers = _MOBILENET_LAYERS
+
+    def __init__(self, n_classes, input_height=224, input_width=224, channels=3, dtype="f32"):
+        if dtype != "f32":
+            raise NotImplementedError("the MobileNet encoder is built in fp32 only")
+        super().__init__(n_classes, input_height, input_width, channels, dtype)
+
+    def intermediate(self, name, n, out="probs", n_points=0):
+        raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")
+
+
+class Fcn32MobilenetModel(Fcn8MobilenetModel):
+    model_name = "fcn_32_mobilenet"
+    _arch = _lib.ARCH_FCN32_MOBILENET
+    _grid_growth = 32
+    _fcn32 = True
+
+
+def fcn_8_mobilenet(n_classes, input_height=224, input_width=224, channels=3, dtype="f32"):
+    """networks/fcn.py:181-185 (defaults 224x224 as there)."""
+    return Fcn8MobilenetModel(n_classes, input_height=input_height, input_width=input_width, channels=channels,
+                              dtype=dtype)
+
+
+def fcn_32_mobilenet(n_classes, input_height=224, input_width=224, channels=3, dtype="f32"):
+    """networks/fcn.py:188-192."""
+    return Fcn32MobilenetModel(n_classes, input_height=input_height, input_width=input_width, channels=channels,
+                               dtype=dtype)
 
 
 def fcn_32(n_classes, encoder=None, input_height=416, input_width=608, channels=3, dtype="f32"):

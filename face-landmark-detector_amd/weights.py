@@ -79,6 +79,78 @@ def synth_vgg_weights(n_classes: int = 68, seed: int = 2, channels: int = 3, fcn
     return p
 
 
+MOBILENET_PW = (64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 1024)  # networks/mobilenet.py:80-102
+
+
+def mobilenet_param_shapes(n_classes: int, channels: int = 3, fcn32: bool = False) -> dict:
+    """fcn_8_mobilenet / fcn_32_mobilenet: Keras layer names of networks/mobilenet.py; BN under `<layer>_bn`."""
+    shapes = {}
+
+    def bn(name, c):
+        for t in ("gamma", "beta", "moving_mean", "moving_variance"):
+            shapes["%s/%s" % (name, t)] = (c,)
+
+    shapes["conv1/kernel"] = (3, 3, channels, 32)
+    bn("conv1_bn", 32)
+    cin = 32
+    for i, f in enumerate(MOBILENET_PW, 1):
+        shapes["conv_dw_%d/depthwise_kernel" % i] = (3, 3, cin, 1)
+        bn("conv_dw_%d_bn" % i, cin)
+        shapes["conv_pw_%d/kernel" % i] = (1, 1, cin, f)
+        bn("conv_pw_%d_bn" % i, f)
+        cin = f
+    shapes["fc6/kernel"] = (7, 7, 1024, FC_WIDTH)
+    shapes["fc6/bias"] = (FC_WIDTH,)
+    shapes["fc7/kernel"] = (1, 1, FC_WIDTH, FC_WIDTH)
+    shapes["fc7/bias"] = (FC_WIDTH,)
+    shapes["score5/kernel"] = (1, 1, FC_WIDTH, n_classes)
+    shapes["score5/bias"] = (n_classes,)
+    if fcn32:
+        shapes["up32/kernel"] = (64, 64, n_classes, n_classes)
+        return shapes
+    shapes["score4/kernel"] = (1, 1, 512, n_classes)
+    shapes["score4/bias"] = (n_classes,)
+    shapes["score3/kernel"] = (1, 1, 256, n_classes)
+    shapes["score3/bias"] = (n_classes,)
+    shapes["up5/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up4/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up3/kernel"] = (16, 16, n_classes, n_classes)
+    return shapes
+
+
+def synth_mobilenet_weights(n_classes: int = 68, seed: int = 2, channels: int = 3, fcn32: bool = False) -> dict:
+    """Seeded synthetic parameters for the MobileNet variants."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shp in mobilenet_param_shapes(n_classes, channels, fcn32).items():
+        layer, tensor = name.split("/")
+        if tensor == "bias":
+            p[name] = rng.standard_normal(shp, dtype=np.float32) * np.float32(0.01)
+        elif tensor == "gamma":
+            p[name] = rng.uniform(0.8, 1.6, shp).astype(np.float32)
+        elif tensor in ("beta", "moving_mean"):
+            p[name] = rng.standard_normal(shp, dtype=np.float32) * np.float32(0.1)
+        elif tensor == "moving_variance":
+            p[name] = rng.uniform(0.5, 1.5, shp).astype(np.float32)
+        elif tensor == "depthwise_kernel":
+            p[name] = rng.standard_normal(shp, dtype=np.float32) * np.float32(np.sqrt(2.0 / 9.0))
+        else:
+            if layer.startswith("up"):
+                kh, kw, co, ci = shp
+                stride = {"up3": 8, "up32": 32}.get(layer, 2)
+                std = np.sqrt(1.0 / ((kh // stride) * (kw // stride) * ci))
+            else:
+                kh, kw, ci, co = shp
+                std = np.sqrt(2.0 / (kh * kw * ci))
+            w = rng.standard_normal(shp, dtype=np.float32) * np.float32(std)
+            if layer == "conv1":
+                w *= np.float32(1.0 / 64.0)
+            if layer.startswith("score"):
+                w *= np.float32(0.125)
+            p[name] = w
+    return p
+
+
 def fcn32_param_shapes(n_classes: int, channels: int = 3) -> dict:
     """fcn_32 (networks/fcn.py:129-150): encoder + fc6 + fc7 + 1x1 classifier + one 64x64/s32 transposed conv."""
     s8 = fcn8_param_shapes(n_classes, channels)
@@ -181,7 +253,9 @@ def load_weights_file(path: str) -> dict:
 def check_params(params: dict, n_classes: int, channels: int = 3, arch: str = "fcn_8") -> None:
     want = {"fcn_32": lambda: fcn32_param_shapes(n_classes, channels),
             "fcn_8_vgg": lambda: vgg_param_shapes(n_classes, channels, False),
-            "fcn_32_vgg": lambda: vgg_param_shapes(n_classes, channels, True)}.get(
+            "fcn_32_vgg": lambda: vgg_param_shapes(n_classes, channels, True),
+            "fcn_8_mobilenet": lambda: mobilenet_param_shapes(n_classes, channels, False),
+            "fcn_32_mobilenet": lambda: mobilenet_param_shapes(n_classes, channels, True)}.get(
                 arch, lambda: fcn8_param_shapes(n_classes, channels))()
     missing = sorted(set(want) - set(params))
     if missing:

@@ -147,8 +147,13 @@ int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x
  * FCN head on several encoders.  `arch` selects the graph; the flm_fcn8_* / flm_fcn32_* calls above are
  * these with arch = FLM_ARCH_FCN8 / FLM_ARCH_FCN32.  Encoder convs arrive in network order in `enc`:
  * 5 layers for the vanilla encoder (BatchNorm tensors required), 13 for VGG16 (block1_conv1 ..
- * block5_conv3, networks/vgg16.py:27-72, no BatchNorm: gamma..var NULL). */
-enum flm_arch { FLM_ARCH_FCN8 = 0, FLM_ARCH_FCN32 = 1, FLM_ARCH_FCN8_VGG = 2, FLM_ARCH_FCN32_VGG = 3 };
+ * block5_conv3, networks/vgg16.py:27-72, no BatchNorm: gamma..var NULL), 27 for MobileNet-v1 (conv1, then
+ * conv_dw_i / conv_pw_i for i = 1..13, networks/mobilenet.py:79-102; no biases: bias NULL; the depthwise
+ * kernels are the Keras (3,3,C,1) tensors). */
+enum flm_arch {
+  FLM_ARCH_FCN8 = 0, FLM_ARCH_FCN32 = 1, FLM_ARCH_FCN8_VGG = 2, FLM_ARCH_FCN32_VGG = 3,
+  FLM_ARCH_FCN8_MOBILENET = 4, FLM_ARCH_FCN32_MOBILENET = 5 /* fp32 only */
+};
 typedef struct flm_fcn_params {
   const flm_conv_params* enc; /* host array of n_enc entries (the pointers inside are device pointers) */
   int n_enc;

@@ -97,6 +97,32 @@ def vgg_encoder_ref(x_nchw, p, dtype):
     return levels
 
 
+def mobilenet_encoder_ref(x_nchw, p, dtype):
+    """networks/mobilenet.py:59-102 (alpha 1, depth_multiplier 1, pretrained=None): conv1 = ZeroPadding2D(1) +
+    Conv2D(32, 3x3, stride 2, valid, no bias) + BN + ReLU6 (:16-29); 13 blocks of ZeroPadding2D(1) +
+    DepthwiseConv2D(3x3, stride s, valid, no bias) + BN + ReLU6 + Conv2D(1x1, no bias) + BN + ReLU6 (:32-56);
+    strides 2 at blocks 2, 4, 6, 12; levels after blocks 1, 3, 5, 11, 13."""
+    def relu6(t):
+        return torch.clamp(t, 0.0, 6.0)
+
+    w = _t(p["conv1/kernel"], dtype).permute(3, 2, 0, 1).contiguous()
+    x = relu6(_bn(F.conv2d(x_nchw, w, None, stride=2, padding=1), p, "conv1_bn", dtype))
+    levels = []
+    for i in range(1, 14):
+        s = 2 if i in (2, 4, 6, 12) else 1
+        dw = _t(p["conv_dw_%d/depthwise_kernel" % i], dtype).permute(2, 3, 0, 1).contiguous()  # (C,1,3,3)
+        x = relu6(_bn(F.conv2d(x, dw, None, stride=s, padding=1, groups=dw.shape[0]), p, "conv_dw_%d_bn" % i, dtype))
+        pw = _t(p["conv_pw_%d/kernel" % i], dtype).permute(3, 2, 0, 1).contiguous()
+        x = relu6(_bn(F.conv2d(x, pw, None), p, "conv_pw_%d_bn" % i, dtype))
+        if i in (1, 3, 5, 11, 13):
+            levels.append(x)
+    return levels
+
+
+def _encoder(name):
+    return {"vgg": vgg_encoder_ref, "mobilenet": mobilenet_encoder_ref}.get(name, vanilla_encoder_ref)
+
+
 def crop_ref(o1, o2):
     """networks/fcn.py:55-86.  The larger map loses its RIGHT columns and BOTTOM rows
     (Cropping2D(((0,0),(0,cx))) then Cropping2D(((0,cy),(0,0)))): the top-left window stays."""
@@ -118,7 +144,7 @@ def fcn8_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, return_int
     """networks/fcn.py:89-122 up to (not including) the softmax.  x: [N,H,W,3] preprocessed.
     encoder="vgg" is fcn_8_vgg (fcn.py:153-157)."""
     x = _t(x_nhwc, dtype).permute(0, 3, 1, 2).contiguous()
-    f1, f2, f3, f4, f5 = (vgg_encoder_ref if encoder == "vgg" else vanilla_encoder_ref)(x, p, dtype)
+    f1, f2, f3, f4, f5 = _encoder(encoder)(x, p, dtype)
     o = torch.relu(_conv(f5, p["fc6/kernel"], p["fc6/bias"], 3, dtype))   # fcn.py:98 7x7 'same'; :99 dropout = id
     fc6 = o
     o = torch.relu(_conv(o, p["fc7/kernel"], p["fc7/bias"], 0, dtype))    # fcn.py:100-101
@@ -147,7 +173,7 @@ def fcn32_logits_ref(x_nhwc: np.ndarray, p: dict, dtype=torch.float32, encoder="
     """networks/fcn.py:129-146 up to the softmax: encoder, fc6, fc7, 1x1 classifier ("seg_feats", :143-144),
     Conv2DTranspose(C, 64x64, stride 32, no bias) (:145-146).  Output grid (H/32 - 1)*32 + 64 = H + 32."""
     x = _t(x_nhwc, dtype).permute(0, 3, 1, 2).contiguous()
-    f5 = (vgg_encoder_ref if encoder == "vgg" else vanilla_encoder_ref)(x, p, dtype)[4]
+    f5 = _encoder(encoder)(x, p, dtype)[4]
     o = torch.relu(_conv(f5, p["fc6/kernel"], p["fc6/bias"], 3, dtype))   # fcn.py:138
     o = torch.relu(_conv(o, p["fc7/kernel"], p["fc7/bias"], 0, dtype))    # fcn.py:140
     o = _conv(o, p["score5/kernel"], p["score5/bias"], 0, dtype)          # fcn.py:143-144

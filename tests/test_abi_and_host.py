@@ -79,11 +79,13 @@ def test_model_object_contract():
     assert isinstance(m, Fcn8Model) and (m.output_height, m.output_width) == (264, 264)
     with pytest.raises(ValueError):
         LANDMARKS_MODELS["fcn_8"](68, input_height=250, input_width=256)
-    for name in ("fcn_8_resnet50", "fcn_8_mobilenet"):   # registry keys of basic_models.py:59-64
+    for name in ("fcn_8_resnet50",):   # registry keys of basic_models.py:59-64
         with pytest.raises(NotImplementedError):
             LANDMARKS_MODELS[name](68, input_height=224, input_width=224)
     v = LANDMARKS_MODELS["fcn_8_vgg"](68, input_height=224, input_width=224)   # built, without the download
     assert (v.model_name, v.output_height, len(v._enc_layers)) == ("fcn_8_vgg", 232, 13)
+    mb = LANDMARKS_MODELS["fcn_8_mobilenet"](68)                       # defaults 224x224 (fcn.py:181)
+    assert (mb.model_name, mb.input_height, mb.output_height, len(mb._enc_layers)) == ("fcn_8_mobilenet", 224, 232, 27)
     v32 = LANDMARKS_MODELS["fcn_32_vgg"](68, input_height=224, input_width=224)
     assert (v32.model_name, v32.output_height) == ("fcn_32_vgg", 256)
 

@@ -214,3 +214,27 @@ def test_vgg_variants(flm):
         got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
         assert got.shape == exp.shape
         assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
+
+
+def test_mobilenet_variants(flm):
+    """fcn_8_mobilenet / fcn_32_mobilenet (networks/fcn.py:181-192 on networks/mobilenet.py:59-114): stride-2
+    conv1, 13 depthwise-separable blocks with BN + ReLU6, 1024-channel f5."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_mobilenet_weights
+    from oracle import fcn_ref
+    rng = np.random.default_rng(34)
+    for name, fcn32, (n, h, w, c) in (("fcn_8_mobilenet", False, (2, 64, 96, 68)),
+                                      ("fcn_32_mobilenet", True, (1, 64, 64, 68)),
+                                      ("fcn_8_mobilenet", False, (1, 224, 224, 68))):
+        params = synth_mobilenet_weights(c, seed=5, fcn32=fcn32)
+        model = LANDMARKS_MODELS[name](c, input_height=h, input_width=w)
+        model.load_weights(params)
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in img])
+        ref = fcn_ref.fcn32_predict_ref if fcn32 else fcn_ref.fcn8_predict_ref
+        exp = ref(x_ref, params, encoder="mobilenet")
+        got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
+        assert got.shape == exp.shape
+        assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
+    with pytest.raises(NotImplementedError):
+        LANDMARKS_MODELS["fcn_8_mobilenet"](68, dtype="bf16")
