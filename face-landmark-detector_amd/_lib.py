@@ -52,6 +52,7 @@ class FcnParams(C.Structure):
 
 
 ARCH_FCN8, ARCH_FCN32, ARCH_FCN8_VGG, ARCH_FCN32_VGG, ARCH_FCN8_MOBILENET, ARCH_FCN32_MOBILENET = 0, 1, 2, 3, 4, 5
+ARCH_FCN8_RESNET50, ARCH_FCN32_RESNET50 = 6, 7
 
 _lib = None
 

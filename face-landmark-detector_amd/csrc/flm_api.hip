@@ -59,14 +59,9 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   const ArchSpec A = arch_spec(arch);
   const size_t es = dtype == FLM_BF16 ? 2 : 4;  // encoder activations, fc6, fc7 are stored in the operand type
   size_t cur = 0;
-  int hh = h, ww = w;
-  for (int i = 0; i < A.n_enc; ++i) {
-    if (A.enc[i].pool || A.enc[i].stride == 2) {
-      hh >>= 1;
-      ww >>= 1;
-    }
-    W.act[i] = take(cur, es * (size_t)n * hh * ww * A.enc[i].cout);
-  }
+  int hs[kMaxEnc], wsz[kMaxEnc];
+  enc_dims(A, h, w, hs, wsz);
+  for (int i = 0; i < A.n_enc; ++i) W.act[i] = take(cur, es * (size_t)n * hs[i] * wsz[i] * A.enc[i].cout);
   for (int k = 0; k < 5; ++k) W.f[k] = W.act[A.f_idx[k]];
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
   W.fc6 = take(cur, es * (size_t)n * h5 * w5 * kFc);
@@ -110,10 +105,13 @@ static int check_fcn8_shape(int n, int h, int w, int C, int dtype) {
 
 static int conv_layer(hipStream_t s, const char* blob, const ConvPack& c, const void* x, void* y, int n, int h,
                       int w, int relu, int pool, int posmajor, int dtype, int out_f32 = 0,
-                      float* splitk_ws = nullptr, size_t splitk_bytes = 0) {
+                      float* splitk_ws = nullptr, size_t splitk_bytes = 0, int stride = 1,
+                      const void* res = nullptr) {
   IgemmDesc d;
   d.bf16 = dtype == FLM_BF16;
   d.out_f32 = out_f32;
+  d.stride = stride;
+  d.res = res;
   d.splitk_ws = splitk_ws;
   d.splitk_ws_bytes = splitk_bytes;
   d.x = x;
@@ -328,43 +326,68 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   float* seg = reinterpret_cast<float*>(ws + W.seg);
 
   // encoder: vanilla (networks/fcn.py:10-51) or VGG16 (networks/vgg16.py:27-72)
-  static const char* const enc_names[kMaxEnc] = {
-      "enc1",  "enc2",  "enc3",  "enc4",  "enc5",  "enc6",  "enc7",  "enc8",  "enc9",  "enc10", "enc11", "enc12", "enc13", "enc14",
-      "enc15", "enc16", "enc17", "enc18", "enc19", "enc20", "enc21", "enc22", "enc23", "enc24", "enc25", "enc26", "enc27"};
-  const bool mobilenet = A.enc[0].kind == ENC_MB_CONV1;
-  if (mobilenet && bf) {
-    set_error("flm_fcn_forward: the MobileNet encoder is built in fp32 only");
+  static char enc_names[kMaxEnc][8];
+  static bool names_done = false;
+  if (!names_done) {
+    for (int i = 0; i < kMaxEnc; ++i) snprintf(enc_names[i], sizeof(enc_names[i]), "enc%d", i + 1);
+    names_done = true;
+  }
+  const bool fp32_only = A.enc[0].kind == ENC_MB_CONV1 || A.enc[0].kind == ENC_RN_CONV1;
+  if (fp32_only && bf) {
+    set_error("flm_fcn_forward: the MobileNet and ResNet50 encoders are built in fp32 only");
     return FLM_ERR_UNSUPPORTED;
   }
-  { ProfScope ps(s, enc_names[0]);
-  if (mobilenet)
-    rc = launch_mb_conv1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
-                         reinterpret_cast<const float*>(blob + L.enc1_scale),
-                         reinterpret_cast<const float*>(blob + L.enc1_shift), reinterpret_cast<float*>(ws + W.act[0]));
-  else
-    rc = launch_enc1(s, x_dev, in_format, n, h, w, reinterpret_cast<const float*>(blob + L.enc1_w),
-                     reinterpret_cast<const float*>(blob + L.enc1_scale),
-                     reinterpret_cast<const float*>(blob + L.enc1_shift), ws + W.act[0], bf, A.enc[0].pool); }
-  if (rc) return rc;
-  const bool half0 = A.enc[0].pool || A.enc[0].stride == 2;
-  int hh = half0 ? h / 2 : h, ww = half0 ? w / 2 : w;
-  for (int i = 1; i < A.n_enc; ++i) {
-    const EncLayer& e = A.enc[i];
-    { ProfScope ps(s, enc_names[i]);
-    if (e.kind == ENC_MB_DW)
-      rc = launch_mb_depthwise(s, reinterpret_cast<const float*>(ws + W.act[i - 1]), n, hh, ww, e.cin, e.stride,
-                               reinterpret_cast<const float*>(blob + L.enc[i].w),
-                               reinterpret_cast<const float*>(blob + L.enc[i].scale),
-                               reinterpret_cast<const float*>(blob + L.enc[i].shift),
-                               reinterpret_cast<float*>(ws + W.act[i]));
-    else
-      rc = conv_layer(s, blob, L.enc[i], ws + W.act[i - 1], ws + W.act[i], n, hh, ww,
-                      /*relu*/ e.kind == ENC_MB_PW ? 2 : 1, e.pool, 0, dtype); }
-    if (rc) return rc;
-    if (e.pool || e.stride == 2) {
-      hh /= 2;
-      ww /= 2;
+  int hs[kMaxEnc], wsz[kMaxEnc];
+  enc_dims(A, h, w, hs, wsz);
+  {
+    int h8 = hs[A.f_idx[2]], h16 = hs[A.f_idx[3]], h32 = hs[A.f_idx[4]];
+    if (h8 != h / 8 || h16 != h / 16 || h32 != h / 32) {
+      set_error("flm_fcn_forward: encoder grid %d/%d/%d does not match the decoder's H/8, H/16, H/32", h8, h16, h32);
+      return FLM_ERR_SHAPE;
     }
+  }
+  for (int i = 0; i < A.n_enc; ++i) {
+    const EncLayer& e = A.enc[i];
+    const int src = e.src >= 0 ? e.src : i - 1;
+    const void* xin = src >= 0 ? static_cast<const void*>(ws + W.act[src]) : x_dev;
+    const int hi = src >= 0 ? hs[src] : h, wi = src >= 0 ? wsz[src] : w;
+    void* yout = ws + W.act[i];
+    const float* w0 = reinterpret_cast<const float*>(blob + (i == 0 ? L.enc1_w : L.enc[i].w));
+    const float* sc0 = reinterpret_cast<const float*>(blob + (i == 0 ? L.enc1_scale : L.enc[i].scale));
+    const float* sh0 = reinterpret_cast<const float*>(blob + (i == 0 ? L.enc1_shift : L.enc[i].shift));
+    ProfScope ps(s, enc_names[i]);
+    switch (e.kind) {
+      case ENC_FIRST3:
+        rc = launch_enc1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, yout, bf, e.pool);
+        break;
+      case ENC_MB_CONV1:
+        rc = launch_mb_conv1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, reinterpret_cast<float*>(yout));
+        break;
+      case ENC_RN_CONV1:
+        rc = launch_rn_conv1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, reinterpret_cast<float*>(yout));
+        break;
+      case ENC_MAXPOOL3:
+        rc = launch_maxpool3(s, reinterpret_cast<const float*>(xin), n, hi, wi, e.cin, reinterpret_cast<float*>(yout));
+        break;
+      case ENC_MB_DW:
+        rc = launch_mb_depthwise(s, reinterpret_cast<const float*>(xin), n, hi, wi, e.cin, e.stride, w0, sc0, sh0,
+                                 reinterpret_cast<float*>(yout));
+        break;
+      case ENC_CONV3:
+        rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu*/ 1, e.pool, 0, dtype);
+        break;
+      case ENC_MB_PW:
+        rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu6*/ 2, 0, 0, dtype);
+        break;
+      case ENC_CONV:
+        rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, e.relu, 0, 0, dtype, 0, nullptr, 0, e.stride,
+                        e.res >= 0 ? ws + W.act[e.res] : nullptr);
+        break;
+      default:
+        set_error("flm_fcn_forward: unknown encoder layer kind %d", e.kind);
+        rc = FLM_ERR_ARG;
+    }
+    if (rc) return rc;
   }
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
   // head (fcn.py:98-103); Dropout is the identity at inference

@@ -32,29 +32,40 @@ constexpr float kBnEps = 1e-3f;  // keras BatchNormalization default epsilon
 // ---- architecture constants (networks/fcn.py:13,34,43,98,100) ------------------------------
 constexpr int kFc = 4096;
 constexpr int kMaxClasses = 96;
-constexpr int kMaxEnc = 27;
+constexpr int kMaxEnc = 64;
 
-// Encoder description.
+// Encoder description: a list of layers; layer i reads the output of layer `src` (default: i-1, or the
+// network input for i = 0) and may add the output of layer `res` before its activation.
 enum EncKind {
-  ENC_FIRST3 = 0,  // 3-channel Conv2D 3x3 'same' + (BN) + ReLU (+ MaxPool 2x2): enc1_kernel
-  ENC_CONV3 = 1,   // Conv2D 3x3 'same' + (BN) + ReLU (+ MaxPool 2x2): igemm_kernel
+  ENC_FIRST3 = 0,    // 3-channel Conv2D 3x3 'same' + (BN) + ReLU (+ MaxPool 2x2): enc1_kernel
+  ENC_CONV3 = 1,     // Conv2D 3x3 'same' + (BN) + ReLU (+ MaxPool 2x2): igemm_kernel
   ENC_MB_CONV1 = 2,  // MobileNet conv1: pad 1, 3x3 stride 2, no bias, BN, ReLU6 (3 -> 32)
   ENC_MB_DW = 3,     // MobileNet depthwise 3x3 (stride 1|2), no bias, BN, ReLU6
-  ENC_MB_PW = 4      // MobileNet pointwise 1x1, no bias, BN, ReLU6: igemm_kernel
+  ENC_MB_PW = 4,     // MobileNet pointwise 1x1, no bias, BN, ReLU6: igemm_kernel
+  ENC_RN_CONV1 = 5,  // ResNet conv1: pad 3, 7x7 stride 2, bias, BN, ReLU (3 -> 64)
+  ENC_MAXPOOL3 = 6,  // MaxPooling2D 3x3 stride 2 'valid' (no parameters)
+  ENC_CONV = 7       // generic Conv2D k x k (k = 1|3, stride 1|2, 'same' when stride 1) + bias + BN (+ residual)
+                     // (+ ReLU): igemm_kernel
 };
 struct EncLayer {
   int cin, cout, bn, pool;
   int kind, stride;
+  int k, relu;   // ENC_CONV: kernel size and whether a ReLU follows
+  int src, res;  // layer indices (-1: previous layer / none)
 };
 struct ArchSpec {
   int n_enc;
   EncLayer enc[kMaxEnc];
-  int f_idx[5];  // index of the layer whose (pooled) output is f1..f5
+  int f_idx[5];  // index of the layer whose (pooled) output is f1..f5 (f1, f2 are not used by the decoders)
   int fcn32;     // one 64x64 stride-32 transposed conv instead of the FCN-8 skip decoder
   int valid;
 };
+// Output grid of every encoder layer for an h x w input.
+void enc_dims(const ArchSpec& A, int h, int w, int* hs, int* ws);
+inline int enc_has_params(const EncLayer& e) { return e.kind != ENC_MAXPOOL3; }
 // FLM_ARCH_FCN8 / FCN32: vanilla_encoder (networks/fcn.py:10-51); *_VGG: get_vgg_encoder (networks/vgg16.py:17-81);
-// *_MOBILENET: get_mobilenet_encoder (networks/mobilenet.py:59-114)
+// *_MOBILENET: get_mobilenet_encoder (networks/mobilenet.py:59-114); *_RESNET50: get_resnet50_encoder
+// (networks/resnet50.py:122-182)
 ArchSpec arch_spec(int arch);
 
 // Geometry of the transposed-conv kernels for a class count C.
@@ -124,6 +135,8 @@ struct IgemmDesc {
   int ldc;      // channel stride of y
   int kh, kw, pad;
   int relu, pool, posmajor;  // relu: 0 none, 1 ReLU, 2 ReLU6
+  int stride;               // 1 (0 = 1); 2 only in the row-major order (ResNet's strided 1x1 convs)
+  const void* res;          // optional residual [n,ho,wo,ldc] added before the activation
   float* splitk_ws;        // optional scratch for split-K partial sums (null: never split)
   size_t splitk_ws_bytes;
 };
@@ -148,6 +161,9 @@ int launch_mb_conv1(hipStream_t s, const void* x, int in_format, int n, int h, i
                     const float* scale, const float* shift, float* y);
 int launch_mb_depthwise(hipStream_t s, const float* x, int n, int h, int w, int c, int stride, const float* wgt,
                         const float* scale, const float* shift, float* y);
+int launch_rn_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
+                    const float* scale, const float* shift, float* y);
+int launch_maxpool3(hipStream_t s, const float* x, int n, int h, int w, int c, float* y);
 
 size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points);
 int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,

@@ -44,10 +44,12 @@ struct IgemmArgs {
   void* y;             // operand type, or fp32 when out_f32
   int out_f32;
   float relu_max;      // upper clamp applied with the ReLU (6 for ReLU6, +inf otherwise)
-  int n, h, w, cin;
+  int n, h, w, cin;    // input grid
+  int ho, wo, stride;  // output grid = ((h + 2*pad - kh) / stride + 1, ...); stride > 1 only with MMAP 0
+  const void* res;     // optional residual [n,ho,wo,ldc] (operand type) added before the ReLU
   int cout, ldc;
   int kh, kw, pad;
-  int M;        // n*h*w
+  int M;        // n*ho*wo
   int K;        // kh*kw*cin
   int mtiles, ntiles;
   int cpt;      // 128-byte channel chunks per tap = cin/32 (fp32) or cin/64 (bf16)
@@ -155,10 +157,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int m = m0 + r0 + 32 * j;
     pv[j] = m < a.M;
     const int mm = pv[j] ? m : 0;
-    if (MMAP == 0) {
-      px[j] = mm % a.w;
-      py[j] = (mm / a.w) % a.h;
-      pn[j] = mm / (a.w * a.h);
+    if (MMAP == 0) {  // (py, px) are INPUT coordinates of the filter centre: output pixel * stride
+      px[j] = (mm % a.wo) * a.stride;
+      py[j] = ((mm / a.wo) % a.ho) * a.stride;
+      pn[j] = mm / (a.wo * a.ho);
     } else if (MMAP == 1) {
       const int q = mm >> 2, d = mm & 3, wp = a.w >> 1, hp = a.h >> 1;
       px[j] = 2 * (q % wp) + (d & 1);
@@ -402,7 +404,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float u = fmaf(acc[i][j][r], sc, sh);
-          if (RELU) u = fminf(fmaxf(u, 0.f), a.relu_max);
           if (a.ksplit > 1) {
             if (cok && m < a.M) a.part[((size_t)blockIdx.y * a.M + m) * a.ldc + col] = acc[i][j][r];
             continue;
@@ -416,6 +417,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
               orow = (size_t)m;
             }
             const size_t o = orow * a.ldc + col;
+            if (MMAP == 0 && a.res) {  // residual add before the activation (ResNet bottlenecks)
+              if (BF) u += (float)__builtin_bit_cast(__bf16, reinterpret_cast<const unsigned short*>(a.res)[o]);
+              else u += reinterpret_cast<const float*>(a.res)[o];
+            }
+            if (RELU) u = fminf(fmaxf(u, 0.f), a.relu_max);
             if (BF && !a.out_f32) reinterpret_cast<unsigned short*>(a.y)[o] = f2bf(u);
             else reinterpret_cast<float*>(a.y)[o] = u;
           }
@@ -484,13 +490,23 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
     set_error("igemm: pooled layer needs even h,w (got %dx%d)", d.h, d.w);
     return FLM_ERR_SHAPE;
   }
-  const long long M = (long long)d.n * d.h * d.w;
+  const int stride = d.stride > 0 ? d.stride : 1;
+  const int ho = (d.h + 2 * d.pad - d.kh) / stride + 1, wo = (d.w + 2 * d.pad - d.kw) / stride + 1;
+  if ((stride != 1 || d.res) && (d.pool || d.posmajor)) {
+    set_error("igemm: stride / residual are only built for the row-major pixel order");
+    return FLM_ERR_UNSUPPORTED;
+  }
+  if (stride == 1 && (ho != d.h || wo != d.w)) {
+    set_error("igemm: stride-1 layers must be 'same' (k=%dx%d pad=%d)", d.kh, d.kw, d.pad);
+    return FLM_ERR_SHAPE;
+  }
+  const long long M = (long long)d.n * ho * wo;
   if (M <= 0 || M > (1ll << 30)) {
     set_error("igemm: pixel count %lld out of range", M);
     return FLM_ERR_SHAPE;
   }
   // byte offsets inside the kernel are 32-bit
-  if ((long long)M * d.cin * es >= (1ll << 32) || (long long)d.coutpad * d.kh * d.kw * d.cin >= (1ll << 31)) {
+  if ((long long)d.n * d.h * d.w * d.cin * es >= (1ll << 32) || (long long)d.coutpad * d.kh * d.kw * d.cin >= (1ll << 31)) {
     set_error("igemm: tensor exceeds the 32-bit offset range (split the batch)");
     return FLM_ERR_SHAPE;
   }
@@ -499,6 +515,7 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   a.out_f32 = d.bf16 ? d.out_f32 : 1;
   a.relu_max = d.relu == 2 ? 6.0f : 3.402823466e38f;
   a.n = d.n; a.h = d.h; a.w = d.w; a.cin = d.cin; a.cout = d.cout; a.ldc = d.ldc;
+  a.ho = ho; a.wo = wo; a.stride = stride; a.res = d.res;
   a.kh = d.kh; a.kw = d.kw; a.pad = d.pad;
   a.M = (int)M;
   a.K = d.kh * d.kw * d.cin;
@@ -509,7 +526,7 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   a.ksplit = 1;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
-  if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && tiles <= 64 && a.cpt >= 32 &&
+  if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && !d.res && tiles <= 64 && a.cpt >= 32 &&
       (!d.bf16 || d.out_f32)) {
     int ks = 256 / tiles;
     if (ks > 8) ks = 8;

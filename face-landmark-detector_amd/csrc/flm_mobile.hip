@@ -85,6 +85,100 @@ __global__ __launch_bounds__(256) void mb_depthwise_kernel(const float* __restri
   }
 }
 
+// ---- ResNet50 stem (reference networks/resnet50.py:145-152) ------------------------------------------
+//   conv1: ZeroPadding2D(3) + Conv2D(64, 7x7, stride 2, bias) + BN + ReLU; then MaxPooling2D(3x3, stride 2, valid)
+// conv1: one thread per (output pixel, 8 output channels); the 147x64 filter sits in LDS (37.6 KB).
+template <bool U8>
+__global__ __launch_bounds__(256) void rn_conv1_kernel(const void* __restrict__ xin, const float* __restrict__ wgt,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ y, int n,
+                                                       int h, int w) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [147][64]
+  for (int i = threadIdx.x; i < 147 * 64; i += 256) wl[i] = wgt[i];
+  __syncthreads();
+  const int ho = h >> 1, wo = w >> 1;
+  const size_t total = (size_t)n * ho * wo * 8;
+  const float mean_rgb[3] = {123.68f, 116.779f, 103.939f};
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+    const int og = (int)(t & 7);
+    const size_t pix = t >> 3;
+    const int x = (int)(pix % wo), yy = (int)((pix / wo) % ho), img = (int)(pix / ((size_t)wo * ho));
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+      const int iy = 2 * yy + ky - 3;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ix = 2 * x + kx - 3;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        const size_t ip = ((size_t)img * h + iy) * w + ix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float v;
+          if (U8) v = (float)reinterpret_cast<const uint8_t*>(xin)[ip * 3 + (2 - c)] - mean_rgb[c];
+          else v = reinterpret_cast<const float*>(xin)[ip * 3 + c];
+          const float* wr = wl + ((ky * 7 + kx) * 3 + c) * 64 + og * 8;
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+        }
+      }
+    }
+    float* d = y + pix * 64 + og * 8;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) d[o] = fmaxf(fmaf(acc[o], scale[og * 8 + o], shift[og * 8 + o]), 0.f);
+  }
+}
+
+// MaxPooling2D(3x3, stride 2, 'valid'): one thread per (output pixel, 4 channels)
+__global__ __launch_bounds__(256) void maxpool3_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
+                                                       int w, int c) {
+  const int ho = (h - 3) / 2 + 1, wo = (w - 3) / 2 + 1, c4 = c >> 2;
+  const size_t total = (size_t)n * ho * wo * c4;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+    const int cq = (int)(t % c4);
+    const size_t pix = t / c4;
+    const int ox = (int)(pix % wo), oy = (int)((pix / wo) % ho), img = (int)(pix / ((size_t)wo * ho));
+    float4 m = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 v =
+            *reinterpret_cast<const float4*>(x + (((size_t)img * h + 2 * oy + ky) * w + 2 * ox + kx) * c + 4 * cq);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    *reinterpret_cast<float4*>(y + pix * c + 4 * cq) = m;
+  }
+}
+
+int launch_rn_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
+                    const float* scale, const float* shift, float* y) {
+  const size_t total = (size_t)n * (h / 2) * (w / 2) * 8;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const size_t lds = sizeof(float) * 147 * 64;
+  if (in_format == FLM_IN_U8_BGR) rn_conv1_kernel<true><<<blocks, 256, lds, s>>>(x, wgt, scale, shift, y, n, h, w);
+  else if (in_format == FLM_IN_F32_RGB) rn_conv1_kernel<false><<<blocks, 256, lds, s>>>(x, wgt, scale, shift, y, n, h, w);
+  else {
+    set_error("resnet conv1: unknown input format %d", in_format);
+    return FLM_ERR_ARG;
+  }
+  FLM_LAUNCH_CHECK("rn_conv1_kernel");
+  return FLM_OK;
+}
+
+int launch_maxpool3(hipStream_t s, const float* x, int n, int h, int w, int c, float* y) {
+  if ((c & 3) || h < 3 || w < 3) {
+    set_error("maxpool3: unsupported shape c=%d %dx%d", c, h, w);
+    return FLM_ERR_SHAPE;
+  }
+  const size_t total = (size_t)n * ((h - 3) / 2 + 1) * ((w - 3) / 2 + 1) * (c / 4);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  maxpool3_kernel<<<blocks, 256, 0, s>>>(x, y, n, h, w, c);
+  FLM_LAUNCH_CHECK("maxpool3_kernel");
+  return FLM_OK;
+}
+
 int launch_mb_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
                     const float* scale, const float* shift, float* y) {
   const size_t total = (size_t)n * (h / 2) * (w / 2) * 4;

@@ -20,16 +20,26 @@ ConvTGeom convt_geom(int C, int dtype) {
   return g;
 }
 
+static EncLayer mk(int kind, int cin, int cout, int bn, int pool, int stride, int k = 3, int relu = 1, int src = -1,
+                   int res = -1) {
+  EncLayer e;
+  e.kind = kind; e.cin = cin; e.cout = cout; e.bn = bn; e.pool = pool; e.stride = stride;
+  e.k = k; e.relu = relu; e.src = src; e.res = res;
+  return e;
+}
+
 ArchSpec arch_spec(int arch) {
   ArchSpec A;
   A.valid = 1;
-  A.fcn32 = (arch == FLM_ARCH_FCN32 || arch == FLM_ARCH_FCN32_VGG || arch == FLM_ARCH_FCN32_MOBILENET);
+  A.n_enc = 0;
+  A.fcn32 = (arch == FLM_ARCH_FCN32 || arch == FLM_ARCH_FCN32_VGG || arch == FLM_ARCH_FCN32_MOBILENET ||
+             arch == FLM_ARCH_FCN32_RESNET50);
   if (arch == FLM_ARCH_FCN8 || arch == FLM_ARCH_FCN32) {
     // vanilla_encoder, networks/fcn.py:10-51: 5 x (pad 1, conv 3x3, BN, ReLU, pool); F = 64,128,256,256,256
     const int f[6] = {3, 64, 128, 256, 256, 256};
     A.n_enc = 5;
     for (int i = 0; i < 5; ++i) {
-      A.enc[i] = EncLayer{f[i], f[i + 1], 1, 1, i == 0 ? ENC_FIRST3 : ENC_CONV3, 1};
+      A.enc[i] = mk(i == 0 ? ENC_FIRST3 : ENC_CONV3, f[i], f[i + 1], 1, 1, 1);
       A.f_idx[i] = i;
     }
   } else if (arch == FLM_ARCH_FCN8_VGG || arch == FLM_ARCH_FCN32_VGG) {
@@ -39,7 +49,7 @@ ArchSpec arch_spec(int arch) {
     int cin = 3, k = 0;
     for (int bl = 0; bl < 5; ++bl)
       for (int c = 0; c < blocks[bl]; ++c) {
-        A.enc[k] = EncLayer{cin, ch[bl], 0, c == blocks[bl] - 1, k == 0 ? ENC_FIRST3 : ENC_CONV3, 1};
+        A.enc[k] = mk(k == 0 ? ENC_FIRST3 : ENC_CONV3, cin, ch[bl], 0, c == blocks[bl] - 1, 1);
         if (c == blocks[bl] - 1) A.f_idx[bl] = k;
         cin = ch[bl];
         ++k;
@@ -51,20 +61,83 @@ ArchSpec arch_spec(int arch) {
     const int pw[13] = {64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 1024};
     const int st[13] = {1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1, 2, 1};
     int k = 0, cin = 32;
-    A.enc[k++] = EncLayer{3, 32, 1, 0, ENC_MB_CONV1, 2};
+    A.enc[k++] = mk(ENC_MB_CONV1, 3, 32, 1, 0, 2);
     for (int b = 0; b < 13; ++b) {
-      A.enc[k++] = EncLayer{cin, cin, 1, 0, ENC_MB_DW, st[b]};
-      A.enc[k++] = EncLayer{cin, pw[b], 1, 0, ENC_MB_PW, 1};
+      A.enc[k++] = mk(ENC_MB_DW, cin, cin, 1, 0, st[b]);
+      A.enc[k++] = mk(ENC_MB_PW, cin, pw[b], 1, 0, 1, 1, 2);
       cin = pw[b];
     }
     A.n_enc = k;  // 27
     const int fb[5] = {1, 3, 5, 11, 13};
     for (int i = 0; i < 5; ++i) A.f_idx[i] = 2 * fb[i];  // index of conv_pw_<block>
+  } else if (arch == FLM_ARCH_FCN8_RESNET50 || arch == FLM_ARCH_FCN32_RESNET50) {
+    // get_resnet50_encoder, networks/resnet50.py:145-170: conv1 7x7 s2 + BN + ReLU, MaxPooling2D(3x3, s2, valid),
+    // stages 2..5 of bottleneck blocks [3,4,6,3]; a stage's first block has a 1x1 shortcut conv and (stages 3..5)
+    // stride 2 on its first 1x1 and on the shortcut (:81-118); f3/f4/f5 = outputs of stages 3/4/5
+    int k = 0;
+    A.enc[k++] = mk(ENC_RN_CONV1, 3, 64, 1, 0, 2, 7, 1);
+    A.enc[k++] = mk(ENC_MAXPOOL3, 64, 64, 0, 0, 2);
+    const int nblk[4] = {3, 4, 6, 3};
+    const int width[4] = {64, 128, 256, 512};
+    int cin = 64, last = k - 1;
+    for (int st = 0; st < 4; ++st) {
+      const int f1 = width[st], f3 = 4 * width[st];
+      for (int b = 0; b < nblk[st]; ++b) {
+        const int s = (b == 0 && st > 0) ? 2 : 1;
+        int shortcut = last;  // identity block: the block input
+        if (b == 0) {         // conv_block: 1x1 (stride s) + BN on the shortcut, no ReLU
+          A.enc[k] = mk(ENC_CONV, cin, f3, 1, 0, s, 1, 0, last, -1);
+          shortcut = k++;
+        }
+        A.enc[k] = mk(ENC_CONV, cin, f1, 1, 0, s, 1, 1, last, -1); ++k;   // branch2a
+        A.enc[k] = mk(ENC_CONV, f1, f1, 1, 0, 1, 3, 1, k - 1, -1); ++k;   // branch2b
+        A.enc[k] = mk(ENC_CONV, f1, f3, 1, 0, 1, 1, 1, k - 1, shortcut);  // branch2c + add + ReLU
+        last = k++;
+        cin = f3;
+      }
+      A.f_idx[st + 1] = last;
+    }
+    A.f_idx[0] = 0;
+    A.n_enc = k;  // 2 + 16*3 + 4 = 54
   } else {
     A.valid = 0;
-    A.n_enc = 0;
   }
   return A;
+}
+
+void enc_dims(const ArchSpec& A, int h, int w, int* hs, int* ws) {
+  for (int i = 0; i < A.n_enc; ++i) {
+    const EncLayer& e = A.enc[i];
+    const int src = e.src >= 0 ? e.src : i - 1;
+    const int hi = src >= 0 ? hs[src] : h, wi = src >= 0 ? ws[src] : w;
+    int ho = hi, wo = wi;
+    switch (e.kind) {
+      case ENC_FIRST3:
+      case ENC_CONV3:
+        if (e.pool) { ho = hi / 2; wo = wi / 2; }
+        break;
+      case ENC_MB_CONV1:
+      case ENC_RN_CONV1:
+        ho = hi / 2; wo = wi / 2;  // pad k/2, stride 2 on an even grid
+        break;
+      case ENC_MB_DW:
+        ho = hi / e.stride; wo = wi / e.stride;
+        break;
+      case ENC_MAXPOOL3:
+        ho = (hi - 3) / 2 + 1; wo = (wi - 3) / 2 + 1;  // 'valid'
+        break;
+      case ENC_CONV: {
+        const int pad = e.k / 2;
+        ho = (hi + 2 * pad - e.k) / e.stride + 1;
+        wo = (wi + 2 * pad - e.k) / e.stride + 1;
+        break;
+      }
+      default:
+        break;
+    }
+    hs[i] = ho;
+    ws[i] = wo;
+  }
 }
 
 static size_t take(size_t& cur, size_t bytes) {
@@ -92,7 +165,7 @@ Fcn8Pack fcn8_pack_layout(int C, int dtype, int arch) {
   const int fcn32 = A.fcn32;
   const int es = dtype == FLM_BF16 ? 2 : 4;
   size_t cur = 0;
-  L.enc1_w = take(cur, sizeof(float) * 64 * 32);
+  L.enc1_w = take(cur, sizeof(float) * 64 * 147);  // 64x32 (3x3 first convs) .. 147x64 (ResNet conv1)
   L.enc1_scale = take(cur, sizeof(float) * 64);
   L.enc1_shift = take(cur, sizeof(float) * 64);
   for (int i = 1; i < A.n_enc; ++i) {
@@ -106,6 +179,10 @@ Fcn8Pack fcn8_pack_layout(int C, int dtype, int arch) {
       L.enc[i] = c;
     } else if (e.kind == ENC_MB_PW) {
       L.enc[i] = conv_pack(cur, 1, 1, 0, e.cin, e.cout, (int)align_up(e.cout, 128), es);
+    } else if (e.kind == ENC_CONV) {
+      L.enc[i] = conv_pack(cur, e.k, e.k, e.k / 2, e.cin, e.cout, (int)align_up(e.cout, 128), es);
+    } else if (e.kind == ENC_MAXPOOL3) {
+      L.enc[i] = ConvPack{};
     } else {
       L.enc[i] = conv_pack(cur, 3, 3, 1, e.cin, e.cout, (int)align_up(e.cout, 128), es);
     }
@@ -225,45 +302,46 @@ static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c,
 
 int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pack& L, char* blob) {
   const ArchSpec& A = L.spec;
-  if (!p.enc || p.n_enc != A.n_enc) {
-    set_error("flm_fcn_pack: this architecture has %d encoder convs, got %d", A.n_enc, p.n_enc);
+  int n_params = 0;
+  for (int i = 0; i < A.n_enc; ++i) n_params += enc_has_params(A.enc[i]);
+  if (!p.enc || p.n_enc != n_params) {
+    set_error("flm_fcn_pack: this architecture has %d encoder convs, got %d", n_params, p.n_enc);
     return FLM_ERR_ARG;
   }
+  int pi = 0;
   for (int i = 0; i < A.n_enc; ++i) {
-    const flm_conv_params& q = p.enc[i];
-    const bool needs_bias = A.enc[i].kind == ENC_FIRST3 || A.enc[i].kind == ENC_CONV3;
+    const EncLayer& e = A.enc[i];
+    if (!enc_has_params(e)) continue;
+    flm_conv_params q = p.enc[pi++];
+    const bool needs_bias = e.kind == ENC_FIRST3 || e.kind == ENC_CONV3 || e.kind == ENC_RN_CONV1 || e.kind == ENC_CONV;
     if (!q.kernel || (needs_bias && !q.bias)) {
-      set_error("flm_fcn_pack: encoder conv %d lacks kernel or bias", i + 1);
+      set_error("flm_fcn_pack: encoder conv %d lacks kernel or bias", pi);
       return FLM_ERR_ARG;
     }
-    if (A.enc[i].bn && (!q.gamma || !q.beta || !q.mean || !q.var)) {
-      set_error("flm_fcn_pack: encoder conv %d lacks BatchNormalization tensors", i + 1);
+    if (e.bn && (!q.gamma || !q.beta || !q.mean || !q.var)) {
+      set_error("flm_fcn_pack: encoder conv %d lacks BatchNormalization tensors", pi);
       return FLM_ERR_ARG;
     }
-  }
-  // first conv (3 input channels): its own kernel layout
-  {
-    flm_conv_params q = p.enc[0];
-    if (!A.enc[0].bn) q.gamma = q.beta = q.mean = q.var = nullptr;
-    if (A.enc[0].kind == ENC_MB_CONV1) {  // Keras (3,3,3,32) is already [27][32]
-      FLM_HIP(hipMemcpyAsync(blob + L.enc1_w, q.kernel, sizeof(float) * 27 * 32, hipMemcpyDeviceToDevice, s));
-      pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 32, 32);
-    } else {
-      pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(q.kernel, (float*)(blob + L.enc1_w));
-      FLM_LAUNCH_CHECK("pack_enc1_kernel");
-      pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+    if (!e.bn) q.gamma = q.beta = q.mean = q.var = nullptr;
+    if (i == 0) {  // first conv (3 input channels): its own kernel layouts
+      if (e.kind == ENC_MB_CONV1) {  // Keras (3,3,3,32) is already [27][32]
+        FLM_HIP(hipMemcpyAsync(blob + L.enc1_w, q.kernel, sizeof(float) * 27 * 32, hipMemcpyDeviceToDevice, s));
+        pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 32, 32);
+      } else if (e.kind == ENC_RN_CONV1) {  // Keras (7,7,3,64) is already [147][64]
+        FLM_HIP(hipMemcpyAsync(blob + L.enc1_w, q.kernel, sizeof(float) * 147 * 64, hipMemcpyDeviceToDevice, s));
+        pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+      } else {
+        pack_enc1_kernel<<<cdiv(64 * 32, 256), 256, 0, s>>>(q.kernel, (float*)(blob + L.enc1_w));
+        FLM_LAUNCH_CHECK("pack_enc1_kernel");
+        pack_affine_kernel<<<1, 64, 0, s>>>(q, (float*)(blob + L.enc1_scale), (float*)(blob + L.enc1_shift), 64, 64);
+      }
+      FLM_LAUNCH_CHECK("pack_affine_kernel");
+      continue;
     }
-    FLM_LAUNCH_CHECK("pack_affine_kernel");
-  }
-  for (int i = 1; i < A.n_enc; ++i) {
-    flm_conv_params q = p.enc[i];
-    if (!A.enc[i].bn) q.gamma = q.beta = q.mean = q.var = nullptr;
-    if (A.enc[i].kind == ENC_MB_DW) {  // Keras depthwise kernel (3,3,C,1) is already [9][C]
-      FLM_HIP(hipMemcpyAsync(blob + L.enc[i].w, q.kernel, sizeof(float) * 9 * A.enc[i].cin,
-                             hipMemcpyDeviceToDevice, s));
-      pack_affine_kernel<<<cdiv(A.enc[i].cin, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),
-                                                                 (float*)(blob + L.enc[i].shift), A.enc[i].cin,
-                                                                 A.enc[i].cin);
+    if (e.kind == ENC_MB_DW) {  // Keras depthwise kernel (3,3,C,1) is already [9][C]
+      FLM_HIP(hipMemcpyAsync(blob + L.enc[i].w, q.kernel, sizeof(float) * 9 * e.cin, hipMemcpyDeviceToDevice, s));
+      pack_affine_kernel<<<cdiv(e.cin, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),
+                                                          (float*)(blob + L.enc[i].shift), e.cin, e.cin);
       FLM_LAUNCH_CHECK("pack_affine_kernel");
       continue;
     }

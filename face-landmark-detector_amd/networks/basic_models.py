@@ -6,7 +6,8 @@ registry lists only ImageNet-backbone variants (whose constructors download weig
 broken 'default'; it has no entry for the vanilla FCN-8 the hot path is built on, so this
 registry adds 'fcn_8' and points 'default' at it.
 """
-from .fcn import fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg, fcn_8_mobilenet, fcn_32_mobilenet
+from .fcn import (fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg, fcn_8_mobilenet, fcn_32_mobilenet, fcn_8_resnet50,
+                  fcn_32_resnet50)
 
 
 def _not_built(name, why):
@@ -21,7 +22,8 @@ LANDMARKS_MODELS = {
     "fcn_8": fcn_8,
     "fcn_32": fcn_32,
     "default": fcn_8,
-    "fcn_8_resnet50": _not_built("fcn_8_resnet50", _BACKBONE),
+    "fcn_8_resnet50": fcn_8_resnet50,     # likewise, fp32
+    "fcn_32_resnet50": fcn_32_resnet50,
     "fcn_8_mobilenet": fcn_8_mobilenet,   # likewise, fp32
     "fcn_32_mobilenet": fcn_32_mobilenet,
     "fcn_8_vgg": fcn_8_vgg,      # built without the ImageNet download (pretrained=None)

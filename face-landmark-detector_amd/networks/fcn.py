@@ -328,6 +328,46 @@ def fcn_32_mobilenet(n_classes, input_height=224, input_width=224, channels=3, d
                                dtype=dtype)
 
 
+_RESNET_LAYERS = tuple((conv, bn) for conv, bn, _k, _ci, _co in W.resnet50_conv_layers())
+
+
+class Fcn8Resnet50Model(Fcn8Model):
+    """fcn_8 on the ResNet50 encoder (networks/fcn.py:167-171, networks/resnet50.py:122-182), built without the
+    ImageNet download: 7x7/s2 stem + 3x3/s2 'valid' max-pool (a 256x256 input gives 63x63 at stage 2) and 16
+    bottleneck blocks with fused residual adds; f3/f4/f5 have 512/1024/2048 channels.  Tensors carry the Keras
+    layer names (`res3a_branch2b/kernel|bias`, `bn3a_branch2b/gamma|...`).  fp32 only."""
+    model_name = "fcn_8_resnet50"
+    _arch = _lib.ARCH_FCN8_RESNET50
+    _enc_layers = _RESNET_LAYERS
+
+    def __init__(self, n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
+        if dtype != "f32":
+            raise NotImplementedError("the ResNet50 encoder is built in fp32 only")
+        super().__init__(n_classes, input_height, input_width, channels, dtype)
+
+    def intermediate(self, name, n, out="probs", n_points=0):
+        raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")
+
+
+class Fcn32Resnet50Model(Fcn8Resnet50Model):
+    model_name = "fcn_32_resnet50"
+    _arch = _lib.ARCH_FCN32_RESNET50
+    _grid_growth = 32
+    _fcn32 = True
+
+
+def fcn_8_resnet50(n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
+    """networks/fcn.py:167-171."""
+    return Fcn8Resnet50Model(n_classes, input_height=input_height, input_width=input_width, channels=channels,
+                             dtype=dtype)
+
+
+def fcn_32_resnet50(n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
+    """networks/fcn.py:174-178."""
+    return Fcn32Resnet50Model(n_classes, input_height=input_height, input_width=input_width, channels=channels,
+                              dtype=dtype)
+
+
 def fcn_32(n_classes, encoder=None, input_height=416, input_width=608, channels=3, dtype="f32"):
     """Signature of networks/fcn.py:129-130 (vanilla encoder only, as fcn_8)."""
     if encoder not in (None, "vanilla", "vanilla_encoder"):

@@ -151,6 +151,86 @@ def synth_mobilenet_weights(n_classes: int = 68, seed: int = 2, channels: int = 
     return p
 
 
+RESNET_STAGES = ((2, "abc", 64), (3, "abcd", 128), (4, "abcdef", 256), (5, "abc", 512))  # networks/resnet50.py:154-170
+
+
+def resnet50_conv_layers():
+    """(conv layer name, bn layer name, kernel size, cin, cout) in the order the C library consumes them:
+    conv1, then per block [shortcut `branch1` if the block is a conv_block], branch2a, 2b, 2c."""
+    layers = [("conv1", "bn_conv1", 7, 3, 64)]
+    cin = 64
+    for stage, blocks, f in RESNET_STAGES:
+        for b in blocks:
+            base, bn = "res%d%s_branch" % (stage, b), "bn%d%s_branch" % (stage, b)
+            if b == "a":
+                layers.append((base + "1", bn + "1", 1, cin, 4 * f))
+            layers.append((base + "2a", bn + "2a", 1, cin, f))
+            layers.append((base + "2b", bn + "2b", 3, f, f))
+            layers.append((base + "2c", bn + "2c", 1, f, 4 * f))
+            cin = 4 * f
+    return layers
+
+
+def resnet50_param_shapes(n_classes: int, channels: int = 3, fcn32: bool = False) -> dict:
+    """fcn_8_resnet50 / fcn_32_resnet50: Keras layer names of networks/resnet50.py (conv + separate bn layers)."""
+    shapes = {}
+    for conv, bn, k, cin, cout in resnet50_conv_layers():
+        shapes[conv + "/kernel"] = (k, k, cin, cout)
+        shapes[conv + "/bias"] = (cout,)
+        for t in ("gamma", "beta", "moving_mean", "moving_variance"):
+            shapes["%s/%s" % (bn, t)] = (cout,)
+    shapes["fc6/kernel"] = (7, 7, 2048, FC_WIDTH)
+    shapes["fc6/bias"] = (FC_WIDTH,)
+    shapes["fc7/kernel"] = (1, 1, FC_WIDTH, FC_WIDTH)
+    shapes["fc7/bias"] = (FC_WIDTH,)
+    shapes["score5/kernel"] = (1, 1, FC_WIDTH, n_classes)
+    shapes["score5/bias"] = (n_classes,)
+    if fcn32:
+        shapes["up32/kernel"] = (64, 64, n_classes, n_classes)
+        return shapes
+    shapes["score4/kernel"] = (1, 1, 1024, n_classes)
+    shapes["score4/bias"] = (n_classes,)
+    shapes["score3/kernel"] = (1, 1, 512, n_classes)
+    shapes["score3/bias"] = (n_classes,)
+    shapes["up5/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up4/kernel"] = (4, 4, n_classes, n_classes)
+    shapes["up3/kernel"] = (16, 16, n_classes, n_classes)
+    return shapes
+
+
+def synth_resnet50_weights(n_classes: int = 68, seed: int = 2, channels: int = 3, fcn32: bool = False) -> dict:
+    """Seeded synthetic parameters for the ResNet50 variants.  The last BN of every block gets a small gamma so
+    the residual sums stay O(1) through 16 blocks."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shp in resnet50_param_shapes(n_classes, channels, fcn32).items():
+        layer, tensor = name.split("/")
+        if tensor == "bias":
+            p[name] = rng.standard_normal(shp, dtype=np.float32) * np.float32(0.01)
+        elif tensor == "gamma":
+            g = rng.uniform(0.8, 1.2, shp).astype(np.float32)
+            p[name] = g * np.float32(0.3) if layer.endswith("2c") else g
+        elif tensor in ("beta", "moving_mean"):
+            p[name] = rng.standard_normal(shp, dtype=np.float32) * np.float32(0.1)
+        elif tensor == "moving_variance":
+            p[name] = rng.uniform(0.5, 1.5, shp).astype(np.float32)
+        else:
+            if layer.startswith("up"):
+                kh, kw, co, ci = shp
+                stride = {"up3": 8, "up32": 32}.get(layer, 2)
+                std = np.sqrt(1.0 / ((kh // stride) * (kw // stride) * ci))
+            else:
+                kh, kw, ci, co = shp
+                std = np.sqrt(2.0 / (kh * kw * ci))
+            w = rng.standard_normal(shp, dtype=np.float32) * np.float32(std)
+            if layer == "conv1":
+                w *= np.float32(1.0 / 64.0)
+            if layer.startswith("score"):
+                w *= np.float32(0.125)
+            p[name] = w
+    return p
+
+
 def fcn32_param_shapes(n_classes: int, channels: int = 3) -> dict:
     """fcn_32 (networks/fcn.py:129-150): encoder + fc6 + fc7 + 1x1 classifier + one 64x64/s32 transposed conv."""
     s8 = fcn8_param_shapes(n_classes, channels)
@@ -255,7 +335,9 @@ def check_params(params: dict, n_classes: int, channels: int = 3, arch: str = "f
             "fcn_8_vgg": lambda: vgg_param_shapes(n_classes, channels, False),
             "fcn_32_vgg": lambda: vgg_param_shapes(n_classes, channels, True),
             "fcn_8_mobilenet": lambda: mobilenet_param_shapes(n_classes, channels, False),
-            "fcn_32_mobilenet": lambda: mobilenet_param_shapes(n_classes, channels, True)}.get(
+            "fcn_32_mobilenet": lambda: mobilenet_param_shapes(n_classes, channels, True),
+            "fcn_8_resnet50": lambda: resnet50_param_shapes(n_classes, channels, False),
+            "fcn_32_resnet50": lambda: resnet50_param_shapes(n_classes, channels, True)}.get(
                 arch, lambda: fcn8_param_shapes(n_classes, channels))()
     missing = sorted(set(want) - set(params))
     if missing:

@@ -149,10 +149,13 @@ int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x
  * 5 layers for the vanilla encoder (BatchNorm tensors required), 13 for VGG16 (block1_conv1 ..
  * block5_conv3, networks/vgg16.py:27-72, no BatchNorm: gamma..var NULL), 27 for MobileNet-v1 (conv1, then
  * conv_dw_i / conv_pw_i for i = 1..13, networks/mobilenet.py:79-102; no biases: bias NULL; the depthwise
- * kernels are the Keras (3,3,C,1) tensors). */
+ * kernels are the Keras (3,3,C,1) tensors), 53 for ResNet50 (conv1, then per bottleneck block the shortcut
+ * conv `res<stage><block>_branch1` when the block has one, then branch2a, 2b, 2c; networks/resnet50.py:
+ * 145-170; every conv has bias and BatchNorm). */
 enum flm_arch {
   FLM_ARCH_FCN8 = 0, FLM_ARCH_FCN32 = 1, FLM_ARCH_FCN8_VGG = 2, FLM_ARCH_FCN32_VGG = 3,
-  FLM_ARCH_FCN8_MOBILENET = 4, FLM_ARCH_FCN32_MOBILENET = 5 /* fp32 only */
+  FLM_ARCH_FCN8_MOBILENET = 4, FLM_ARCH_FCN32_MOBILENET = 5, /* fp32 only */
+  FLM_ARCH_FCN8_RESNET50 = 6, FLM_ARCH_FCN32_RESNET50 = 7    /* fp32 only */
 };
 typedef struct flm_fcn_params {
   const flm_conv_params* enc; /* host array of n_enc entries (the pointers inside are device pointers) */

@@ -119,8 +119,39 @@ def mobilenet_encoder_ref(x_nchw, p, dtype):
     return levels
 
 
+def resnet50_encoder_ref(x_nchw, p, dtype):
+    """networks/resnet50.py:145-170 (pretrained=None): ZeroPadding2D(3) + Conv2D(64, 7x7, s2) + BN + ReLU +
+    MaxPooling2D(3x3, s2, valid); stages 2..5 of bottleneck blocks (conv_block :81-118 with a 1x1 shortcut conv,
+    stride on branch2a and the shortcut; identity_block :33-78); every Conv2D has a bias.  Returns
+    [f1-like, f2-like, f3, f4, f5]; only f3..f5 feed the FCN decoders (f1 is pre-BN and f2 one-side padded in
+    the reference, and unused)."""
+    def cbn(x, conv, bn, k, stride, relu, res=None):
+        w = _t(p[conv + "/kernel"], dtype).permute(3, 2, 0, 1).contiguous()
+        y = F.conv2d(x, w, _t(p[conv + "/bias"], dtype), stride=stride, padding=k // 2)
+        y = _bn(y, p, bn, dtype)
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if relu else y
+
+    x = cbn(x_nchw, "conv1", "bn_conv1", 7, 2, True)
+    f1 = x
+    x = F.max_pool2d(x, 3, 2)
+    levels = [f1]
+    for stage, blocks in ((2, "abc"), (3, "abcd"), (4, "abcdef"), (5, "abc")):
+        for b in blocks:
+            base, bn = "res%d%s_branch" % (stage, b), "bn%d%s_branch" % (stage, b)
+            s = 2 if (b == "a" and stage > 2) else 1
+            shortcut = cbn(x, base + "1", bn + "1", 1, s, False) if b == "a" else x
+            y = cbn(x, base + "2a", bn + "2a", 1, s, True)
+            y = cbn(y, base + "2b", bn + "2b", 3, 1, True)
+            x = cbn(y, base + "2c", bn + "2c", 1, 1, True, res=shortcut)
+        levels.append(x)
+    return levels
+
+
 def _encoder(name):
-    return {"vgg": vgg_encoder_ref, "mobilenet": mobilenet_encoder_ref}.get(name, vanilla_encoder_ref)
+    return {"vgg": vgg_encoder_ref, "mobilenet": mobilenet_encoder_ref,
+            "resnet50": resnet50_encoder_ref}.get(name, vanilla_encoder_ref)
 
 
 def crop_ref(o1, o2):

@@ -79,9 +79,11 @@ def test_model_object_contract():
     assert isinstance(m, Fcn8Model) and (m.output_height, m.output_width) == (264, 264)
     with pytest.raises(ValueError):
         LANDMARKS_MODELS["fcn_8"](68, input_height=250, input_width=256)
-    for name in ("fcn_8_resnet50",):   # registry keys of basic_models.py:59-64
-        with pytest.raises(NotImplementedError):
-            LANDMARKS_MODELS[name](68, input_height=224, input_width=224)
+    rn = LANDMARKS_MODELS["fcn_8_resnet50"](68)                        # defaults 416x608 (fcn.py:167)
+    assert (rn.model_name, rn.input_width, rn.output_width, len(rn._enc_layers)) == ("fcn_8_resnet50", 608, 616, 53)
+    # every key of the reference's registry (basic_models.py:59-64) builds
+    for key in ("fcn_8_resnet50", "fcn_8_mobilenet", "fcn_8_vgg", "default"):
+        assert key in LANDMARKS_MODELS
     v = LANDMARKS_MODELS["fcn_8_vgg"](68, input_height=224, input_width=224)   # built, without the download
     assert (v.model_name, v.output_height, len(v._enc_layers)) == ("fcn_8_vgg", 232, 13)
     mb = LANDMARKS_MODELS["fcn_8_mobilenet"](68)                       # defaults 224x224 (fcn.py:181)

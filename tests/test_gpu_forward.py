@@ -238,3 +238,26 @@ def test_mobilenet_variants(flm):
         assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
     with pytest.raises(NotImplementedError):
         LANDMARKS_MODELS["fcn_8_mobilenet"](68, dtype="bf16")
+
+
+def test_resnet50_variants(flm):
+    """fcn_8_resnet50 / fcn_32_resnet50 (networks/fcn.py:167-178 on networks/resnet50.py:122-182): 7x7/s2 stem,
+    3x3/s2 valid max-pool (odd 63x63 grid at 256x256), 16 bottleneck blocks with strided 1x1 convs and fused
+    residual adds, 2048-channel f5."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_resnet50_weights
+    from oracle import fcn_ref
+    rng = np.random.default_rng(35)
+    for name, fcn32, (n, h, w, c) in (("fcn_8_resnet50", False, (2, 64, 96, 68)),
+                                      ("fcn_32_resnet50", True, (1, 64, 64, 68)),
+                                      ("fcn_8_resnet50", False, (1, 256, 256, 68))):
+        params = synth_resnet50_weights(c, seed=6, fcn32=fcn32)
+        model = LANDMARKS_MODELS[name](c, input_height=h, input_width=w)
+        model.load_weights(params)
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in img])
+        ref = fcn_ref.fcn32_predict_ref if fcn32 else fcn_ref.fcn8_predict_ref
+        exp = ref(x_ref, params, encoder="resnet50")
+        got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
+        assert got.shape == exp.shape
+        assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
