@@ -23,6 +23,7 @@ SOURCES = [
     "flm_pack.hip",
     "flm_enc1.hip",
     "flm_igemm.hip",
+    "flm_igemm_bf16.hip",
     "flm_convt.hip",
     "flm_decode.hip",
     "flm_misc.hip",

@@ -141,8 +141,19 @@ int flm_debug_query(const char* key, int arg) {
 
 int flm_set_tuning(const char* key, int value) {
   if (!key) return FLM_ERR_ARG;
-  (void)value;  // no knobs are wired at the moment; the entry point stays for tools/tune.py
   if (!strcmp(key, "none")) return FLM_OK;
+  if (!strcmp(key, "bf16_big_tiles")) {  // 256-row bf16 implicit-GEMM tiles on/off (A/B runs of tools/tune.py)
+    flm::igemm_bf16_big_enable(value);
+    return FLM_OK;
+  }
+  if (!strcmp(key, "bf16_group_n")) {  // weight panels per tile group of the 256-row kernel (0: default)
+    if (value < 0 || value > 32 || (value & (value - 1))) {
+      set_error("flm_set_tuning: bf16_group_n must be 0 or a power of two <= 32");
+      return FLM_ERR_ARG;
+    }
+    flm::igemm_bf16_group_n(value);
+    return FLM_OK;
+  }
   set_error("flm_set_tuning: unknown key '%s'", key);
   return FLM_ERR_ARG;
 }

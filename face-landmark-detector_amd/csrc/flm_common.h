@@ -142,6 +142,8 @@ struct IgemmDesc {
 };
 int launch_igemm(hipStream_t s, const IgemmDesc& d);
 int igemm_occupancy(size_t lds_bytes);
+void igemm_bf16_big_enable(int on);
+void igemm_bf16_group_n(int gn);
 
 struct ConvTDesc {
   const float* x;     // [n,hi,wi,Cp]

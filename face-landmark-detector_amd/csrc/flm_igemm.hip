@@ -29,54 +29,15 @@
 //      8x8 -- 38 % of its dense MACs multiply zero padding).  Tiles then differ in work (20..49 taps):
 //      every workgroup ranks the tiles by tap count (a few hundred integer ops) and runs the i-th
 //      heaviest and the i-th lightest back to back, so all workgroups carry about the same load.
-#include "flm_common.h"
+#include "flm_igemm_args.h"
 
 namespace flm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-struct IgemmArgs {
-  const void* x;       // fp32 or bf16 [n,h,w,cin]
-  const void* wt;      // same type, [coutpad][K]
-  const float* scale;
-  const float* shift;
-  void* y;             // operand type, or fp32 when out_f32
-  int out_f32;
-  float relu_max;      // upper clamp applied with the ReLU (6 for ReLU6, +inf otherwise)
-  int n, h, w, cin;    // input grid
-  int ho, wo, stride;  // output grid = ((h + 2*pad - kh) / stride + 1, ...); stride > 1 only with MMAP 0
-  const void* res;     // optional residual [n,ho,wo,ldc] (operand type) added before the ReLU
-  int cout, ldc;
-  int kh, kw, pad;
-  int M;        // n*ho*wo
-  int K;        // kh*kw*cin
-  int mtiles, ntiles;
-  int cpt;      // 128-byte channel chunks per tap = cin/32 (fp32) or cin/64 (bf16)
-  int kw_magic; // ceil(65536 / kw): tap / kw == (tap * kw_magic) >> 16 for tap < 64
-  int ksplit;   // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to `part`
-  float* part;  // [ksplit][M][ldc]
-};
-
 constexpr int BM = 128, BN = 128, BK = 32;   // BK in 4-byte units: a k-step is 128 bytes of every row
 constexpr int TILE_F = BM * BK;             // 4-byte units per operand tile (16 KiB)
-
-// Taps of a kh x kw 'same' filter that touch at least one in-bounds pixel for m-tile t in
-// position-major order (positions t*BM/n .. of an h x w map): bit ky*kw+kx.
-__device__ __forceinline__ unsigned long long posmajor_tapmask(int t, int M, int n, int h, int w, int kh, int kw,
-                                                               int pad) {
-  const int m_lo = t * 128, m_hi = (m_lo + 128 < M ? m_lo + 128 : M) - 1;
-  unsigned long long mask = 0;
-  for (int p = m_lo / n; p <= m_hi / n; ++p) {
-    const int y = p / w, x = p % w;
-    for (int ky = 0; ky < kh; ++ky) {
-      if ((unsigned)(y + ky - pad) >= (unsigned)h) continue;
-      for (int kx = 0; kx < kw; ++kx)
-        if ((unsigned)(x + kx - pad) < (unsigned)w) mask |= 1ull << (ky * kw + kx);
-    }
-  }
-  return mask;
-}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
@@ -103,8 +64,6 @@ __device__ __forceinline__ void mfma_slot(const float4& a0, const float4& a1, co
     c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, IDX), f4c(b1, IDX), c11, 0, 0, 0);
   }
 }
-
-__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 template <bool BF, int MMAP, bool RELU>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
@@ -524,6 +483,7 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   a.kw_magic = (65536 + d.kw - 1) / d.kw;
   // split-K for 1x1 layers whose tile grid cannot fill the chip (score5: 32 workgroups at batch 64)
   a.ksplit = 1;
+  a.gm = a.gn = 1;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
   if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && !d.res && tiles <= 64 && a.cpt >= 32 &&
@@ -538,6 +498,11 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   }
   // only whole N tiles that hold stored columns are launched
   a.ntiles = cdiv(d.cout, BN);
+  if (d.bf16) {
+    const int big = launch_igemm_bf16_big(s, a, d.relu, d.pool, d.posmajor, d.coutpad);
+    if (big < 0) return big;
+    if (big == 1) return FLM_OK;
+  }
   int rc = d.bf16 ? dispatch<true>(s, d, a) : dispatch<false>(s, d, a);
   if (rc || a.ksplit <= 1) return rc;
   const size_t total = (size_t)a.M * d.ldc;

@@ -1,0 +1,54 @@
+// Kernel-argument block and index helpers shared by the implicit-GEMM kernels (flm_igemm.hip: 128x128 tiles,
+// fp32 and bf16; flm_igemm_bf16.hip: 256-row tiles for bf16).
+#pragma once
+#include "flm_common.h"
+
+namespace flm {
+
+struct IgemmArgs {
+  const void* x;       // fp32 or bf16 [n,h,w,cin]
+  const void* wt;      // same type, [coutpad][K]
+  const float* scale;
+  const float* shift;
+  void* y;             // operand type, or fp32 when out_f32
+  int out_f32;
+  float relu_max;      // upper clamp applied with the ReLU (6 for ReLU6, +inf otherwise)
+  int n, h, w, cin;    // input grid
+  int ho, wo, stride;  // output grid = ((h + 2*pad - kh) / stride + 1, ...); stride > 1 only with MMAP 0
+  const void* res;     // optional residual [n,ho,wo,ldc] (operand type) added before the ReLU
+  int cout, ldc;
+  int kh, kw, pad;
+  int M;        // n*ho*wo
+  int K;        // kh*kw*cin
+  int mtiles, ntiles;
+  int cpt;      // 128-byte channel chunks per tap = cin/32 (fp32) or cin/64 (bf16)
+  int kw_magic; // ceil(65536 / kw): tap / kw == (tap * kw_magic) >> 16 for tap < 64
+  int ksplit;   // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to `part`
+  float* part;  // [ksplit][M][ldc]
+  int gm, gn;   // flm_igemm_bf16.hip: tiles are dealt in groups of gm x gn (the 32 workgroups resident on one XCD)
+};
+
+// Taps of a kh x kw 'same' filter that touch at least one in-bounds pixel for m-tile t in
+// position-major order (positions t*BM/n .. of an h x w map): bit ky*kw+kx.
+__device__ __forceinline__ unsigned long long posmajor_tapmask(int t, int M, int n, int h, int w, int kh, int kw,
+                                                               int pad, int bm = 128) {
+  const int m_lo = t * bm, m_hi = (m_lo + bm < M ? m_lo + bm : M) - 1;
+  unsigned long long mask = 0;
+  for (int p = m_lo / n; p <= m_hi / n; ++p) {
+    const int y = p / w, x = p % w;
+    for (int ky = 0; ky < kh; ++ky) {
+      if ((unsigned)(y + ky - pad) >= (unsigned)h) continue;
+      for (int kx = 0; kx < kw; ++kx)
+        if ((unsigned)(x + kx - pad) < (unsigned)w) mask |= 1ull << (ky * kw + kx);
+    }
+  }
+  return mask;
+}
+
+__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
+// bf16 layers whose tile grid fills the chip with 256-row tiles (flm_igemm_bf16.hip); returns 1 when it launched,
+// 0 when the shape is left to the 128x128 kernel, < 0 on error.
+int launch_igemm_bf16_big(hipStream_t s, const IgemmArgs& a, int relu, int pool, int posmajor, int coutpad);
+
+}  // namespace flm

@@ -176,6 +176,32 @@ def test_bf16_forward_against_fp32_oracle(flm, weights68):
     assert (cm == probs_ref.reshape(n, 264, 264, c).argmax(-1)).mean() > 0.9
 
 
+def test_bf16_256_row_tiles_equal_128_row_tiles(flm, weights68):
+    """The 256-row bf16 implicit-GEMM tiles (flm_igemm_bf16.hip) consume k in the same order with the same MFMA
+    as the 128x128 kernel, so every intermediate and the probabilities must be bit-identical between the two
+    (ragged M: 3 faces of 96x160 leave partial tiles in every layer; fc6 runs position-major with skipped taps)."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    rng = np.random.default_rng(33)
+    for (n, h, w) in ((3, 96, 160), (5, 256, 256)):
+        model = LANDMARKS_MODELS["fcn_8"](68, input_height=h, input_width=w, dtype="bf16")
+        model.load_weights(weights68)
+        xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        outs = {}
+        try:
+            for mode in (0, 2):
+                _lib.check(lib.flm_set_tuning(b"bf16_big_tiles", mode), "set_tuning")
+                probs = model.forward_device(xd, "probs").cpu().numpy()
+                inter = {k: model.intermediate(k, n, "probs").cpu().numpy() for k in ("f2", "f3", "f4", "f5", "fc6", "fc7")}
+                outs[mode] = (probs, inter)
+        finally:
+            _lib.check(lib.flm_set_tuning(b"bf16_big_tiles", 1), "set_tuning")
+        for k in outs[0][1]:
+            assert np.array_equal(outs[0][1][k], outs[2][1][k]), (k, n, h, w)
+        assert np.array_equal(outs[0][0], outs[2][0])
+
+
 def test_fcn32_forward(flm, weights68):
     """fcn_32 (networks/fcn.py:129-150): 64x64 stride-32 transposed conv, output grid H+32."""
     from flm_amd.networks import LANDMARKS_MODELS
