@@ -133,16 +133,183 @@ __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin,
   }
 }
 
+
+// ---- bf16 variant (BASELINE configs[2]) ----------------------------------------------------------------
+// Same layer on v_mfma_f32_32x32x16_bf16: the fp32 kernel above spends 0.9 ms of matrix time per 512 faces on
+// a layer that is 1.3 % of the network's FLOPs; in bf16 it is a streaming kernel.
+//   * one workgroup = one pooled output row of one face; the whole 4-row halo of that row is staged once, as
+//     bf16 pixels padded to 4 channels (8 bytes), preprocess fused (x - mean in fp32, then one rounding);
+//   * K = 3 filter rows x 16: k = 16*ky + 4*kx + c with kx = 3 and c = 3 carrying zero weights, so the
+//     fragment of lane (row, half) for filter row ky is the 16 bytes of halo pixels x+2*half, x+2*half+1:
+//     two ds_read_b64 (x may be odd), no gather arithmetic; 3 MFMAs per 32x32 tile;
+//   * halo row stride = 16 pixels (mod 32) puts the two image rows of a lane group on disjoint LDS banks.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int enc1_bf16_halo_stride(int w) {
+  int need = ((w / 2 + 31) / 32) * 64 + 4;  // whole strips of 32 pooled pixels + the kx = 2,3 reach of the last lane
+  return need + ((16 - need % 32) + 32) % 32;
+}
+
+constexpr int kEnc1RowsPerWg = 4;  // pooled rows per workgroup: the filter fragments (36 loads per lane) are built once
+
+template <bool U8, bool POOL>
+__global__ __launch_bounds__(256) void enc1_bf16_kernel(const void* __restrict__ xin, const float* __restrict__ w1p,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        unsigned short* __restrict__ f1, int n, int h, int w) {
+  extern __shared__ __attribute__((aligned(16))) char smem_e1[];
+  uint2* halo = reinterpret_cast<uint2*>(smem_e1);  // [4][hs] pixels of 4 bf16
+  const int hs = enc1_bf16_halo_stride(w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hp = h >> 1, wp = w >> 1;
+  const int rgroups = (hp + kEnc1RowsPerWg - 1) / kEnc1RowsPerWg;
+  const int img = blockIdx.x / rgroups, yp_first = (blockIdx.x % rgroups) * kEnc1RowsPerWg;
+  const int lr = lane & 31, lh = lane >> 5;
+  const float mean_rgb[3] = {123.68f, 116.779f, 103.939f};
+
+  // ---- filter fragments: B[k][o], k = 16*ky + 8*lh + e -> (kx = 2*lh + (e>>2), c = e&3).  Column tile j holds the
+  //      channels o = 2*lr + j: a lane then owns two neighbouring channels of a pixel and stores them as one dword
+  //      (a pixel's 64 channels = one 128-byte line per half-wave) ------------------------------------------------
+  bf16x8 bw[3][2];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kx = 2 * lh + (e >> 2), c = e & 3;
+        const float wv = (kx < 3 && c < 3) ? w1p[(2 * lr + j) * 32 + ky * 9 + kx * 3 + c] : 0.f;
+        bw[ky][j][e] = (__bf16)wv;
+      }
+  float sc[2], sh[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sc[j] = scale[2 * lr + j];
+    sh[j] = shift[2 * lr + j];
+  }
+
+  // this lane's conv-output pixel inside a strip of 32 pooled pixels: row r -> quad q, (dy, dx)
+  const int r = 32 * wave + lr;
+  const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
+  unsigned int* f1w = reinterpret_cast<unsigned int*>(f1);  // channel pairs
+
+  for (int yp = yp_first; yp < yp_first + kEnc1RowsPerWg && yp < hp; ++yp) {
+    if (yp != yp_first) __syncthreads();  // the previous row's fragment reads are done
+    // ---- stage the halo: rows 2yp-1..2yp+2, halo column c <-> input column c-1 ------------------------------
+    if (U8 && (w & 3) == 0) {
+      // 4 pixels = 12 bytes = 3 aligned dwords per thread and step
+      const int gpr = w >> 2;  // groups per row
+      for (int e = tid; e < 4 * gpr; e += 256) {
+        const int hr = e / gpr, g = e % gpr;
+        const int iy = 2 * yp - 1 + hr;
+        unsigned d0 = 0, d1 = 0, d2 = 0;
+        const bool ok = (unsigned)iy < (unsigned)h;
+        if (ok) {
+          const unsigned int* p = reinterpret_cast<const unsigned int*>(reinterpret_cast<const uint8_t*>(xin) +
+                                                                        (((size_t)img * h + iy) * w + 4 * g) * 3);
+          d0 = p[0]; d1 = p[1]; d2 = p[2];
+        }
+        const unsigned by[12] = {d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, d0 >> 24, d1 & 255, (d1 >> 8) & 255,
+                                 (d1 >> 16) & 255, d1 >> 24, d2 & 255, (d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (ok) {
+            v[0] = (__bf16)((float)by[3 * k + 2] - mean_rgb[0]);
+            v[1] = (__bf16)((float)by[3 * k + 1] - mean_rgb[1]);
+            v[2] = (__bf16)((float)by[3 * k + 0] - mean_rgb[2]);
+          }
+          halo[hr * hs + 4 * g + k + 1] = __builtin_bit_cast(uint2, v);
+        }
+      }
+      // zero borders: column 0 and columns w+1 .. hs-1
+      const int nz = hs - w;
+      for (int e = tid; e < 4 * nz; e += 256) {
+        const int hr = e / nz, z = e % nz;
+        halo[hr * hs + (z == 0 ? 0 : w + z)] = make_uint2(0u, 0u);
+      }
+    } else {
+      for (int e = tid; e < 4 * hs; e += 256) {
+        const int hr = e / hs, hc = e % hs;
+        const int iy = 2 * yp - 1 + hr, ix = hc - 1;
+        bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) {
+          const size_t pix = ((size_t)img * h + iy) * w + ix;
+          if (U8) {
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(xin) + pix * 3;
+            v[0] = (__bf16)((float)p[2] - mean_rgb[0]);
+            v[1] = (__bf16)((float)p[1] - mean_rgb[1]);
+            v[2] = (__bf16)((float)p[0] - mean_rgb[2]);
+          } else {
+            const float* p = reinterpret_cast<const float*>(xin) + pix * 3;
+            v[0] = (__bf16)p[0]; v[1] = (__bf16)p[1]; v[2] = (__bf16)p[2];
+          }
+        }
+        halo[e] = __builtin_bit_cast(uint2, v);
+      }
+    }
+    __syncthreads();
+
+    for (int xp0 = 0; xp0 < wp; xp0 += 32) {
+      const int x = 2 * (xp0 + q) + dx;  // conv column; halo columns x..x+3
+      f32x16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const uint2* hp_ = halo + (dy + ky) * hs + x + 2 * lh;
+        const uint2 p0 = hp_[0], p1 = hp_[1];
+        const uint4 av = make_uint4(p0.x, p0.y, p1.x, p1.y);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[ky][j], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int xp = xp0 + 8 * wave + 2 * g + lh;
+        if (POOL) {
+          float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0 = fmaxf(v0, fmaf(acc[0][4 * g + e], sc[0], sh[0]));
+            v1 = fmaxf(v1, fmaf(acc[1][4 * g + e], sc[1], sh[1]));
+          }
+          const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v0) |
+                              ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v1) << 16);
+          if (xp < wp) f1w[(((size_t)img * hp + yp) * wp + xp) * 32 + lr] = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v0 = fmaxf(0.f, fmaf(acc[0][4 * g + e], sc[0], sh[0]));
+            const float v1 = fmaxf(0.f, fmaf(acc[1][4 * g + e], sc[1], sh[1]));
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v0) |
+                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v1) << 16);
+            const int y = 2 * yp + (e >> 1), xx = 2 * xp + (e & 1);
+            if (xp < wp) f1w[(((size_t)img * h + y) * w + xx) * 32 + lr] = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool U8>
+static void launch_bf16_u(hipStream_t s, int blocks, const void* x, const float* w1p, const float* scale,
+                          const float* shift, void* f1, int n, int h, int w, int pool) {
+  const size_t lds = (size_t)4 * enc1_bf16_halo_stride(w) * 8;
+  blocks = n * (((h >> 1) + kEnc1RowsPerWg - 1) / kEnc1RowsPerWg);
+  if (pool) enc1_bf16_kernel<U8, true><<<blocks, 256, lds, s>>>(x, w1p, scale, shift, (unsigned short*)f1, n, h, w);
+  else enc1_bf16_kernel<U8, false><<<blocks, 256, lds, s>>>(x, w1p, scale, shift, (unsigned short*)f1, n, h, w);
+}
+
 template <bool U8>
 static void launch_u(hipStream_t s, int blocks, const void* x, const float* w1p, const float* scale, const float* shift,
                      void* f1, int n, int h, int w, int out_bf16, int pool) {
-  if (out_bf16) {
-    if (pool) enc1_kernel<U8, true, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-    else enc1_kernel<U8, true, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-  } else {
-    if (pool) enc1_kernel<U8, false, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-    else enc1_kernel<U8, false, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-  }
+  (void)out_bf16;  // bf16 output: enc1_bf16_kernel
+  if (pool) enc1_kernel<U8, false, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  else enc1_kernel<U8, false, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
 }
 
 int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
@@ -152,6 +319,20 @@ int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w
     return FLM_ERR_SHAPE;
   }
   const int blocks = n * (h >> 1);
+  if (in_format != FLM_IN_U8_BGR && in_format != FLM_IN_F32_RGB) {
+    set_error("enc1: unknown input format %d", in_format);
+    return FLM_ERR_ARG;
+  }
+  if (out_bf16) {
+    if ((size_t)4 * enc1_bf16_halo_stride(w) * 8 > 64 * 1024) {
+      set_error("enc1: input width %d exceeds the bf16 kernel's halo buffer", w);
+      return FLM_ERR_SHAPE;
+    }
+    if (in_format == FLM_IN_U8_BGR) launch_bf16_u<true>(s, blocks, x, w1p, scale, shift, f1, n, h, w, pool);
+    else launch_bf16_u<false>(s, blocks, x, w1p, scale, shift, f1, n, h, w, pool);
+    FLM_LAUNCH_CHECK("enc1_bf16_kernel");
+    return FLM_OK;
+  }
   if (in_format == FLM_IN_U8_BGR) {
     launch_u<true>(s, blocks, x, w1p, scale, shift, f1, n, h, w, out_bf16, pool);
   } else if (in_format == FLM_IN_F32_RGB) {
