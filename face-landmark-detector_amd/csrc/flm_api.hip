@@ -46,6 +46,16 @@ struct ProfScope {
   }
 };
 
+// Landmark mode without the probability tensor (flm_convt.hip): on for the 68-class FCN-8 kernels, top-n decode
+// with n <= 16 (list capacities grow with n), maps below 2^17 pixels.  Knobs for tests / A-B runs.
+static int g_cand_enable = 1;
+static int g_cand_cap_div = 1;  // > 1 shrinks the per-face list (tests force the overflow fallback with it)
+static int g_cand_sub = 4;      // phases per tile in the sampling launch (R of flm_convt.hip)
+static bool landmark_candidates_enabled(const ConvTGeom& g, int fcn32, int decode_mode, int n_points, int oh, int ow) {
+  return g_cand_enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 16 &&
+         convt_candidates_supported(g) && (long long)oh * ow < (1 << 17);
+}
+
 static size_t take(size_t& cur, size_t bytes) {
   size_t o = cur;
   cur = align_up(cur + bytes, 256);
@@ -75,9 +85,20 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   W.ow = w + (A.fcn32 ? 32 : 8);
   W.probs = SIZE_MAX;
   W.decode = SIZE_MAX;
+  W.sub = W.tau = W.cand = W.cand_cnt = SIZE_MAX;
+  W.cand_cap = 0;
   if (out_mode == FLM_OUT_LANDMARKS) {
     W.probs = take(cur, sizeof(float) * (size_t)n * W.oh * W.ow * C);
     W.decode = take(cur, decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
+    if (landmark_candidates_enabled(g, A.fcn32, decode_mode, n_points, W.oh, W.ow)) {
+      const int h3 = h / 8, w3 = w / 8;
+      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3) * 16 * g.MT);  // wave maxima
+      W.tau = take(cur, sizeof(float) * (size_t)n * C);
+      // expected keys per class: the n-th of 1/64 of the pixels ranks about 64*n-th overall; x4 head room
+      W.cand_cap = (int)align_up((size_t)C * 64 * n_points * 4 / g_cand_cap_div, 64);
+      W.cand = take(cur, sizeof(unsigned long long) * (size_t)n * W.cand_cap);
+      W.cand_cnt = take(cur, sizeof(unsigned) * ((size_t)n + 1));
+    }
   }
   W.total = cur;
   return W;
@@ -144,6 +165,26 @@ int flm_set_tuning(const char* key, int value) {
   if (!strcmp(key, "none")) return FLM_OK;
   if (!strcmp(key, "bf16_big_tiles")) {  // 256-row bf16 implicit-GEMM tiles on/off (A/B runs of tools/tune.py)
     flm::igemm_bf16_big_enable(value);
+    return FLM_OK;
+  }
+  if (!strcmp(key, "landmark_candidates")) {  // 0: always materialise the probabilities and decode them
+    g_cand_enable = value != 0;
+    return FLM_OK;
+  }
+  if (!strcmp(key, "candidate_sub_phases")) {
+    if (value < 1 || value > 16) {
+      set_error("flm_set_tuning: candidate_sub_phases must be in [1,16]");
+      return FLM_ERR_ARG;
+    }
+    g_cand_sub = value;
+    return FLM_OK;
+  }
+  if (!strcmp(key, "candidate_cap_div")) {  // shrink the candidate lists (tests of the overflow fallback)
+    if (value < 1) {
+      set_error("flm_set_tuning: candidate_cap_div must be >= 1");
+      return FLM_ERR_ARG;
+    }
+    g_cand_cap_div = value;
     return FLM_OK;
   }
   if (!strcmp(key, "bf16_group_n")) {  // weight panels per tile group of the 256-row kernel (0: default)
@@ -290,6 +331,11 @@ int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_c
   if (!name || check_fcn8_shape(n, h, w, n_classes, dtype)) return -1;
   const Fcn8Ws W = fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points);
   if (name[0] == 'f' && name[1] >= '1' && name[1] <= '5' && name[2] == 0) return (int64_t)W.f[name[1] - '1'];
+  if (!strcmp(name, "cand_sub")) return W.sub == SIZE_MAX ? -1 : (int64_t)W.sub;
+  if (!strcmp(name, "cand_tau")) return W.tau == SIZE_MAX ? -1 : (int64_t)W.tau;
+  if (!strcmp(name, "cand_keys")) return W.cand == SIZE_MAX ? -1 : (int64_t)W.cand;
+  if (!strcmp(name, "cand_cnt")) return W.cand_cnt == SIZE_MAX ? -1 : (int64_t)W.cand_cnt;
+  if (!strcmp(name, "cand_cap")) return W.cand == SIZE_MAX ? -1 : (int64_t)W.cand_cap;
   if (!strcmp(name, "fc6")) return (int64_t)W.fc6;
   if (!strcmp(name, "fc7")) return (int64_t)W.fc7;
   if (!strcmp(name, "score5")) return (int64_t)W.score5;
@@ -459,17 +505,46 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     ProfScope ps(s, "up3");
     return launch_convt(s, t);
   }
-  // landmarks: probs to the workspace, then the decode (utils/metrics.py:102-109)
+  // landmarks (utils/metrics.py:102-109)
   float* probs = reinterpret_cast<float*>(ws + W.probs);
+  const unsigned* gate = nullptr;
+  if (W.cand != SIZE_MAX) {
+    // top-n without the probability tensor (flm_convt.hip): thresholds from the phase-(0,0) sub-map, candidate
+    // keys from the full launch, exact selection; then the materialising path below runs gated on the overflow flag
+    float* sub = reinterpret_cast<float*>(ws + W.sub);
+    float* tau = reinterpret_cast<float*>(ws + W.tau);
+    unsigned* cnt = reinterpret_cast<unsigned*>(ws + W.cand_cnt);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + W.cand);
+    FLM_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned) * ((size_t)n + 1), s));
+    ConvTDesc ts = t;
+    ts.y = sub; ts.epilogue = 4; ts.sub = g_cand_sub;
+    { ProfScope ps(s, "up3_sub");
+    rc = launch_convt(s, ts); }
+    if (rc) return rc;
+    { ProfScope ps(s, "tau");
+    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi), 16 * L.g.MT, C,
+                         n_points, tau); }
+    if (rc) return rc;
+    ConvTDesc tc = t;
+    tc.y = nullptr; tc.epilogue = 3; tc.tau = tau; tc.cand = cand; tc.cand_cnt = cnt; tc.cand_cap = W.cand_cap;
+    { ProfScope ps(s, "up3");
+    rc = launch_convt(s, tc); }
+    if (rc) return rc;
+    { ProfScope ps(s, "decode");
+    rc = launch_cand_merge(s, cand, cnt, n, W.ow, C, n_points, thresh, W.cand_cap, static_cast<double*>(out_dev)); }
+    if (rc) return rc;
+    gate = cnt + n;  // overflow flag: non-zero -> redo this batch through the probability tensor
+    t.gate = gate;
+  }
   t.y = probs;
   t.epilogue = 1;
-  { ProfScope ps(s, "up3");
+  { ProfScope ps(s, gate ? "up3_fallback" : "up3");
   rc = launch_convt(s, t); }
   if (rc) return rc;
-  ProfScope ps(s, "decode");
+  ProfScope ps(s, gate ? "decode_fallback" : "decode");
   return launch_decode(s, probs, n, W.oh, W.ow, C, C, decode_mode, n_points, thresh,
                        static_cast<double*>(out_dev), ws + W.decode,
-                       decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
+                       decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points), nullptr, gate);
 }
 
 int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const void* x_dev,

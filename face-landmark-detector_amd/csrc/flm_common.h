@@ -109,6 +109,9 @@ struct Fcn8Ws {
   size_t splitk_bytes;
   size_t probs;   // logits/probs when they are not the call's output (else == SIZE_MAX)
   size_t decode;  // decode partials
+  // landmark mode without the probability tensor (flm_convt.hip); cand == SIZE_MAX when not used
+  size_t sub, tau, cand, cand_cnt;
+  int cand_cap;
   size_t total;
   int oh, ow;
 };
@@ -154,10 +157,21 @@ struct ConvTDesc {
   int ho, wo;         // output grid after the crop (<= s*(hi+1))
   int s;              // stride; kernel = 2s
   int ldy;            // channel stride of y (C for the final layer, Cp for score buffers)
-  int epilogue;       // 0 raw (+skip), 1 softmax probs, 2 argmax class map
+  int epilogue;       // 0 raw (+skip), 1 softmax probs, 2 argmax class map, 3 top-n candidates (no map written),
+                      // 4 per-wave class maxima of a sampling launch (sub > 0)
   ConvTGeom g;
+  // landmark mode without the probability tensor (see flm_convt.hip); all zero / null otherwise
+  int sub = 0;                         // > 0: sampling launch, `sub` phases per tile, compact [n][sub][hi+1][wi+1][C] output
+  const float* tau = nullptr;          // [n][C] thresholds (epilogue 3)
+  unsigned long long* cand = nullptr;  // [n][cand_cap] candidate keys
+  unsigned* cand_cnt = nullptr;        // [n] + overflow flag at [n]
+  int cand_cap = 0;
+  const unsigned* gate = nullptr;      // launch is a no-op unless *gate != 0
 };
 int launch_convt(hipStream_t s, const ConvTDesc& d);
+int convt_candidates_supported(const ConvTGeom& g);
+int convt_sample_slots(const ConvTGeom& g, int hi, int wi);
+int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau);
 
 int launch_mb_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
                     const float* scale, const float* shift, float* y);
@@ -169,7 +183,10 @@ int launch_maxpool3(hipStream_t s, const float* x, int n, int h, int w, int c, f
 
 size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points);
 int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,
-                  float thresh, double* out, void* ws, size_t ws_bytes);
+                  float thresh, double* out, void* ws, size_t ws_bytes, float* tau_out = nullptr,
+                  const unsigned* gate = nullptr);
+int launch_cand_merge(hipStream_t s, const unsigned long long* cand, unsigned* cand_cnt, int n, int w, int l,
+                      int n_points, float thresh, int cap, double* out);
 
 int launch_preprocess(hipStream_t s, const uint8_t* img, int n, int h, int w, int norm, float* out);
 int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, float* m);

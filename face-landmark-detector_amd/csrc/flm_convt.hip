@@ -21,6 +21,23 @@
 // and streams the phase's weights, pre-packed in fragment order, through a double-buffered LDS
 // ring (lane-linear ds_read_b128, conflict-free by construction).  For a fixed a0 consecutive b0
 // write 8 consecutive output pixels = one 2176-byte run at C=68.
+//
+// Landmark mode without the probability tensor (template CAND, epilogue 3).  The top-n decode
+// (utils/metrics.py:66-77) needs, per face and class, only the n largest probabilities of the 264x264 map:
+//   1. a sampling launch computes R of the 64 phases per tile of input positions (R/64 of the work; which
+//      phases is a fixed function of the tile index, spread over all 64: the phases are separate filters, so
+//      a sample from one phase alone is not representative of the map).  It writes no map either: every
+//      wave keeps the per-class maximum of its 16*NT*R sampled pixels (epilogue 4), and cand_tau_kernel
+//      (flm_decode.hip) takes tau[face][class] = the n-th largest of the face's 36..72 wave maxima.  Those
+//      are values of n distinct pixels of the full map, so at least n pixels are >= tau and every member of
+//      the true top n is;
+//   2. the full launch keeps its probabilities in registers and appends (value, class, pixel) keys of the
+//      pixels with p >= tau (and p > 0: zero weights cannot move a centroid) to an LDS list -- about 64*n of
+//      the 69,696 pixels per class -- which the workgroup flushes to its face's list with one atomic;
+//   3. cand_merge_kernel (flm_decode.hip) selects the exact top n from the list, same keys and tie rule as
+//      the decode of the materialised map.
+// A list that overflows (flat maps: everything ties with tau) raises a flag; the materialising launch and
+// the ordinary decode follow in the stream, gated on that flag, so the result is exact in every case.
 #include "flm_common.h"
 
 namespace flm {
@@ -36,7 +53,25 @@ struct ConvTArgs {
   int n, hi, wi, ho, wo, s, ldy, epilogue;
   int C, Cp;
   int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
+  int ppf;  // > 0: positions per face padded to a multiple of the workgroup's tile (a workgroup never spans two faces)
+  int ls;   // log2(s): the strides of the reference's decoders are 2, 8 and 32
+  int nb;   // phases b0 computed per phase row (s, or 1 for the sub-sampled launch)
+  int sub;  // > 0: sampling launch: a workgroup computes `sub` phases chosen from its tile index (not a phase row);
+            // epilogue 1 writes them compactly (pixel index (r, i0, j0) on a sub x (hi+1) x (wi+1) grid), epilogue 4
+            // only the per-wave class maxima: y = unsigned [n][4 * tiles per face][16*MT] float bit patterns
+  const float* tau;           // [n][C] candidate thresholds (epilogue 3)
+  unsigned long long* cand;   // [n][cand_cap] keys: order_bits(p) << 32 | class << 17 | pixel
+  unsigned* cand_cnt;         // [n] entries appended per face; cand_cnt[n] = overflow flag
+  int cand_cap;
+  const unsigned* gate;       // non-null: the launch does nothing unless *gate != 0
 };
+
+constexpr int kCandWaveCap = 512;  // candidate keys one wave can hold in LDS (256 pixels x 68 classes pass through it)
+
+__device__ __forceinline__ unsigned cand_order_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
 
 constexpr int GCH_F32 = 6, GCH_BF16 = 3;  // k groups per LDS chunk (bf16: smaller chunks, fewer staging registers)
 
@@ -49,8 +84,12 @@ __device__ __forceinline__ float softmax_exp(float t) {
   else return expf(t);
 }
 
-template <int MT, int G, bool BF, int NT>
+// MODE: 0 = epilogues 0/1/2 (maps), 1 = epilogue 3 (top-n candidates), 2 = epilogue 4 (sampling launch: wave maxima)
+template <int MT, int G, bool BF, int NT, int MODE>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
+  constexpr bool CAND = MODE == 1;
+  constexpr bool SAMPLE = MODE == 2;
+  if (a.gate && *a.gate == 0) return;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr int NCH = (G + GCH - 1) / GCH;
   constexpr int CHUNK_F4 = GCH * MT * 64;             // float4 per full chunk
@@ -60,8 +99,22 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int a0 = blockIdx.y;
+  // candidate keys: one private LDS region per wave, filled through a wave-uniform counter (no atomics)
+  unsigned long long* cwave = reinterpret_cast<unsigned long long*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4) + wave * kCandWaveCap;
+  float* tau_s = reinterpret_cast<float*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 + sizeof(unsigned long long) * 4 * kCandWaveCap);  // [16*MT]
+  unsigned wcnt = 0;
+  // sampling launch (epilogue 4): per-wave class maxima as float bit patterns (p >= 0: unsigned order = float order)
+  unsigned* wmax = reinterpret_cast<unsigned*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 +
+                                               (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0)) +
+                   wave * 16 * MT;
+  if (SAMPLE)
+    for (int c = lane; c < 16 * MT; c += 64) wmax[c] = 0u;
+
   const int s = a.s;
+  // Phase (a0, b0) of iteration IT of this workgroup: phase row blockIdx.y, b0 = IT; in the sampling launch the
+  // IT-th entry of the tile's list -- an odd stride walks all s*s phases before repeating.
+  const int tile_pf = a.sub ? (int)(blockIdx.x % (a.ppf / (64 * NT))) : 0;
+#define FLM_PHASE(IT) (a.sub ? (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)) : ((int)blockIdx.y * s + (IT)))
 
   // ---- this lane's NT input positions (NT pixel tiles of 16 per wave: the phase's weights, streamed once
   //      per workgroup, then serve 64*NT positions) --------------------------------------------------
@@ -71,11 +124,29 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int p = (blockIdx.x * 4 + wave) * 16 * NT + nt * 16 + r;
-    pvalid[nt] = p < a.P;
-    const int pp = pvalid[nt] ? p : 0;
-    j0[nt] = pp % wi1;
-    i0[nt] = (pp / wi1) % hi1;
-    img[nt] = pp / (wi1 * hi1);
+    if (a.ppf > 0) {
+      const int pl = p % a.ppf;
+      img[nt] = p / a.ppf;
+      pvalid[nt] = pl < wi1 * hi1 && img[nt] < a.n;
+      const int pp = pvalid[nt] ? pl : 0;
+      if (!pvalid[nt]) img[nt] = 0;
+      j0[nt] = pp % wi1;
+      i0[nt] = pp / wi1;
+    } else {
+      pvalid[nt] = p < a.P;
+      const int pp = pvalid[nt] ? p : 0;
+      j0[nt] = pp % wi1;
+      i0[nt] = (pp / wi1) % hi1;
+      img[nt] = pp / (wi1 * hi1);
+    }
+  }
+  // candidate mode: thresholds of this workgroup's face for the 4*MT classes of this lane (16m + 4q + e)
+  const int wg_img = CAND ? (blockIdx.x * 64 * NT) / (a.ppf > 0 ? a.ppf : 1) : 0;
+  if (CAND) {
+    // thresholds of this workgroup's face, clamped to FLT_MIN so that p >= tau implies p > 0 (zero weights cannot
+    // move a centroid; a class left with fewer than n keys is caught by cand_merge_kernel)
+    if (tid < 16 * MT)
+      tau_s[tid] = (tid < a.C && wg_img < a.n) ? fmaxf(a.tau[(size_t)wg_img * a.C + tid], 1.17549435e-38f) : 3.402823466e38f;
   }
 
   // ---- X fragments ------------------------------------------------------------------------------------
@@ -112,8 +183,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 
   // ---- weight stream: (b0, chunk) sequence for this phase row ------------------------------------
   const size_t phase_f4 = (size_t)G * MT * 64;
-  const float4* wbase = reinterpret_cast<const float4*>(a.wf) + (size_t)a0 * s * phase_f4;
-  const int total = s * NCH;
+  const float4* wbase = reinterpret_cast<const float4*>(a.wf);
+  const int total = a.nb * NCH;
   // Staging registers are NAMED scalars: an indexed array here (even fully unrolled) is left in scratch
   // memory by hipcc when it is written and read under separate `if (more)` branches.
   static_assert(NLD <= 9, "staging covers at most 9 x 16 bytes per thread");
@@ -135,7 +206,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     const int b0_ = sq_ / NCH, ch_ = sq_ % NCH;                                         \
     const int ng_ = (G - ch_ * GCH) < GCH ? (G - ch_ * GCH) : GCH;                      \
     const int cnt_ = ng_ * MT * 64;                                                     \
-    const float4* src_ = wbase + (size_t)b0_ * phase_f4 + (size_t)ch_ * CHUNK_F4;      \
+    const float4* src_ = wbase + (size_t)FLM_PHASE(b0_) * phase_f4 + (size_t)ch_ * CHUNK_F4; \
     FLM_FOR_ST(FLM_LD1)                                                                 \
   }
 #define FLM_STASH(BUF)                                                                  \
@@ -173,7 +244,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         pv[nt][m][e] = (16 * m + 4 * q + e < a.C) ? softmax_exp<BF>(pv[nt][m][e] - mx) : 0.f;     \
     }                                                                                             \
   }
-#define FLM_EPI_PART2()                                                                           \
+#define FLM_EPI_PART2(EPI_B0)                                                                     \
+  { const int epi_b0 = (EPI_B0);                                                                   \
   if (a.epilogue != 0) {                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
       float sum = 0.f;                                                                            \
@@ -181,17 +253,58 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         sum += pv[nt][m][e];                                                                      \
       sum += __shfl_xor(sum, 16);                                                                 \
       sum += __shfl_xor(sum, 32);                                                                 \
-      const float rs = BF ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;                              \
+      float rs = BF ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;                                    \
+      if (CAND && a.epilogue == 3) {                                                              \
+        const int ph_ = FLM_PHASE(epi_b0);                                                        \
+        const int oy_ = s * i0[nt] + (ph_ >> a.ls), ox_ = s * j0[nt] + (ph_ & (s - 1));                      \
+        if (!(pvalid[nt] && oy_ < a.ho && ox_ < a.wo)) rs = 0.f;                                  \
+      }                                                                                           \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
         pv[nt][m][e] = pv[nt][m][e] * rs;                                                         \
     }                                                                                             \
-  }
+  } }
 #define FLM_EPI_PART3(B0)                                                                         \
   _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                             \
-    const int oy = s * i0[nt] + a0, ox = s * j0[nt] + (B0);                                       \
+    const int ph3_ = FLM_PHASE(B0);                                                               \
+    const int oy = s * i0[nt] + (ph3_ >> a.ls), ox = s * j0[nt] + (ph3_ & (s - 1));                         \
     const bool ovalid = pvalid[nt] && oy < a.ho && ox < a.wo;                                     \
-    const size_t opix = ((size_t)img[nt] * a.ho + oy) * a.wo + ox;                                \
-    if (a.epilogue == 0) {                                                                        \
+    const size_t opix = a.sub ? (((size_t)img[nt] * a.sub + (B0)) * hi1 + i0[nt]) * wi1 + j0[nt]      \
+                              : ((size_t)img[nt] * a.ho + oy) * a.wo + ox;                        \
+    if (SAMPLE) {                                                                                 \
+      /* class maxima over the wave's 16 pixels (lanes r of one q), then one LDS max per class */  \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+        float v = ovalid ? pv[nt][m][e] : 0.f;                                                    \
+        v = fmaxf(v, __shfl_xor(v, 1));                                                           \
+        v = fmaxf(v, __shfl_xor(v, 2));                                                           \
+        v = fmaxf(v, __shfl_xor(v, 4));                                                           \
+        v = fmaxf(v, __shfl_xor(v, 8));                                                           \
+        if (r == 0) atomicMax(&wmax[16 * m + 4 * q + e], __float_as_uint(v));                      \
+      }                                                                                           \
+    } else if (CAND && a.epilogue == 3) {                                                         \
+      /* invalid pixels carry p = 0 (part 2), thresholds are >= FLT_MIN: one compare per value decides */ \
+      const unsigned pixbits = (unsigned)(oy * a.wo + ox);                                        \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                            \
+        const float4 tq = *reinterpret_cast<const float4*>(tau_s + 16 * m + 4 * q);               \
+        unsigned long long mk[4];                                                                 \
+        mk[0] = __ballot(pv[nt][m][0] >= tq.x);                                                   \
+        mk[1] = __ballot(pv[nt][m][1] >= tq.y);                                                   \
+        mk[2] = __ballot(pv[nt][m][2] >= tq.z);                                                   \
+        mk[3] = __ballot(pv[nt][m][3] >= tq.w);                                                   \
+        if (mk[0] | mk[1] | mk[2] | mk[3]) { /* wave-uniform, taken for about one m in eight */   \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+            if (mk[e]) {                                                                          \
+              const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),            \
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u)); \
+              const unsigned slot = wcnt + rank;                                                  \
+              if (((mk[e] >> lane) & 1ull) && slot < (unsigned)kCandWaveCap)                      \
+                cwave[slot] = ((unsigned long long)cand_order_bits(pv[nt][m][e]) << 32) |         \
+                              ((unsigned long long)(16 * m + 4 * q + e) << 17) | pixbits;         \
+              wcnt += __builtin_popcountll(mk[e]);                                                \
+            }                                                                                     \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    } else if (a.epilogue == 0) {                                                                        \
       if (ovalid) {                                                                               \
         float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;                                  \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                          \
@@ -240,7 +353,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   }
 
   int seq = 0;
-  for (int b0 = 0; b0 < s; ++b0) {
+  for (int b0 = 0; b0 < a.nb; ++b0) {
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -255,7 +368,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       // epilogue part of the PREVIOUS phase, issued alongside this chunk's MFMAs
       if (b0 > 0) {
         if (ch == 0) FLM_EPI_PART1()
-        if (ch == (NCH > 1 ? 1 : 0)) FLM_EPI_PART2()
+        if (ch == (NCH > 1 ? 1 : 0)) FLM_EPI_PART2(b0 - 1)
         if (ch == NCH - 1) FLM_EPI_PART3(b0 - 1)
       }
 #pragma unroll
@@ -304,10 +417,34 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   }
   // drain: the last phase's epilogue
   FLM_EPI_PART1()
-  FLM_EPI_PART2()
-  FLM_EPI_PART3(s - 1)
+  FLM_EPI_PART2(a.nb - 1)
+  FLM_EPI_PART3(a.nb - 1)
+  if (SAMPLE) {
+    // (same-wave LDS atomics and reads are ordered; other waves never touch this region)
+    const int tiles_pf = a.ppf / (64 * NT);
+    const int face = blockIdx.x / tiles_pf;
+    unsigned* dst = reinterpret_cast<unsigned*>(a.y) + (((size_t)face * tiles_pf + tile_pf) * 4 + wave) * (16 * MT);
+    if (face < a.n)
+      for (int c = lane; c < 16 * MT; c += 64) dst[c] = wmax[c];
+  }
+  if (CAND && a.epilogue == 3) {
+    // flush this wave's keys to its face's list: one global atomic per wave, coalesced 8-byte stores
+    const unsigned found = __builtin_amdgcn_readfirstlane(wcnt);
+    const unsigned cnt = found < (unsigned)kCandWaveCap ? found : (unsigned)kCandWaveCap;
+    if (wg_img < a.n && found) {
+      unsigned base = 0;
+      if (lane == 0) {
+        base = atomicAdd(&a.cand_cnt[wg_img], cnt);
+        if (found > (unsigned)kCandWaveCap || base + cnt > (unsigned)a.cand_cap) atomicOr(&a.cand_cnt[a.n], 1u);
+      }
+      base = __builtin_amdgcn_readfirstlane(base);
+      for (unsigned i = lane; i < cnt; i += 64)
+        if (base + i < (unsigned)a.cand_cap) a.cand[(size_t)wg_img * a.cand_cap + base + i] = cwave[i];
+    }
+  }
 }
 
+#undef FLM_PHASE
 #undef FLM_EPI_PART1
 #undef FLM_EPI_PART2
 #undef FLM_EPI_PART3
@@ -317,20 +454,37 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #undef FLM_LD1
 #undef FLM_ST1
 
-template <int MT, int G, bool BF, int NT = 1>
-static int launch_t(hipStream_t st, const ConvTArgs& a) {
+template <int MT, int G, bool BF, int NT = 1, int MODE = 0>
+static int launch_t(hipStream_t st, ConvTArgs a) {
+  constexpr bool CAND = MODE == 1;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
-  constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64;
+  constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64 + (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0) +
+                         sizeof(unsigned) * 4 * 16 * MT;
   static bool attr_done = false;
   if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT>),
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  dim3 grid(cdiv(a.P, 64 * NT), a.s);
-  convt_kernel<MT, G, BF, NT><<<grid, 256, lds, st>>>(a);
+  int xblocks = cdiv(a.P, 64 * NT);
+  if (a.ppf > 0) {  // per-face padding: a workgroup's 64*NT positions belong to one face
+    a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 64 * NT) * 64 * NT;
+    xblocks = a.n * (a.ppf / (64 * NT));
+  }
+  dim3 grid(xblocks, a.sub ? 1 : a.s);
+  convt_kernel<MT, G, BF, NT, MODE><<<grid, 256, lds, st>>>(a);
   FLM_LAUNCH_CHECK("convt_kernel");
   return FLM_OK;
+}
+
+// Wave maxima written by the sampling launch per face (epilogue 4): 4 waves per tile of 64*NT positions.
+int convt_sample_slots(const ConvTGeom& g, int hi, int wi) {
+  const int nt = g.bf16 ? 2 : 1;
+  return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt);
+}
+
+int convt_candidates_supported(const ConvTGeom& g) {
+  return g.C == 68 && ((g.bf16 && g.G == 9) || (!g.bf16 && g.G == 17));
 }
 
 int launch_convt(hipStream_t st, const ConvTDesc& d) {
@@ -338,6 +492,14 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
   a.x = d.x; a.wf = d.wf; a.skip = d.skip; a.y = d.y;
   a.n = d.n; a.hi = d.hi; a.wi = d.wi; a.ho = d.ho; a.wo = d.wo; a.s = d.s; a.ldy = d.ldy;
   a.epilogue = d.epilogue; a.C = d.g.C; a.Cp = d.g.Cp;
+  a.sub = d.sub; a.nb = d.sub ? d.sub : d.s;
+  a.ls = 0;
+  while ((1 << a.ls) < d.s) ++a.ls;
+  if ((1 << a.ls) != d.s) {
+    set_error("convt: stride %d is not a power of two", d.s);
+    return FLM_ERR_SHAPE;
+  } a.ppf = (d.sub || d.epilogue == 3) ? 1 : 0;
+  a.tau = d.tau; a.cand = d.cand; a.cand_cnt = d.cand_cnt; a.cand_cap = d.cand_cap; a.gate = d.gate;
   const long long P = (long long)d.n * (d.hi + 1) * (d.wi + 1);
   if (P <= 0 || P > (1ll << 30) || d.ho > d.s * (d.hi + 1) || d.wo > d.s * (d.wi + 1)) {
     set_error("convt: bad geometry n=%d in=%dx%d out=%dx%d s=%d", d.n, d.hi, d.wi, d.ho, d.wo, d.s);
@@ -347,6 +509,21 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
   if (d.epilogue == 0 && (d.ldy & 3)) {
     set_error("convt: raw epilogue needs a channel stride that is a multiple of 4");
     return FLM_ERR_SHAPE;
+  }
+  if (d.epilogue == 3) {
+    if (!convt_candidates_supported(d.g) || !d.tau || !d.cand || !d.cand_cnt || d.cand_cap <= 0 ||
+        (long long)d.ho * d.wo >= (1 << 17)) {
+      set_error("convt: candidate epilogue needs the 68-class kernels, its buffers and a map below 2^17 pixels");
+      return FLM_ERR_UNSUPPORTED;
+    }
+    return d.g.bf16 ? launch_t<5, 9, true, 2, 1>(st, a) : launch_t<5, 17, false, 1, 1>(st, a);
+  }
+  if (d.epilogue == 4) {
+    if (!convt_candidates_supported(d.g) || !d.sub || !d.y) {
+      set_error("convt: the sampling epilogue needs the 68-class kernels, sub > 0 and an output buffer");
+      return FLM_ERR_UNSUPPORTED;
+    }
+    return d.g.bf16 ? launch_t<5, 9, true, 2, 2>(st, a) : launch_t<5, 17, false, 1, 2>(st, a);
   }
   if (d.g.bf16) {
     // two pixel tiles per wave: at 16x the matrix rate the phase weights (45 KiB per 64 positions) are the

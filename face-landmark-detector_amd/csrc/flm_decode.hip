@@ -32,6 +32,8 @@ struct DecodeArgs {
   float thresh;
   void* part;   // ALL: double [n][chunks][l][3]; TOPN: u64 [n][chunks][l][n_points]
   double* out;  // [n][l][2]
+  float* tau_out;        // TOPN only, non-null: write the n-th largest VALUE per (face, landmark) instead of coordinates
+  const unsigned* gate;  // non-null: the launch does nothing unless *gate != 0
 };
 
 __device__ __forceinline__ unsigned order_bits(float v) {
@@ -71,8 +73,32 @@ __device__ __forceinline__ void insert_candidates(unsigned long long& list, unsi
   }
 }
 
+// utils/metrics.py:69-77 on a finished list: float32 sum in ascending value order (= list lanes n-1 .. 0),
+// float64 index-weighted sums, reject when hsum / n_points <= thresh.
+__device__ __forceinline__ void finish_topn(unsigned long long list, int n_points, int w, float thresh, int lane,
+                                            double* out) {
+  float hsum = 0.f;
+  double i0 = 0.0, i1 = 0.0;
+  for (int i = n_points - 1; i >= 0; --i) {
+    const unsigned long long k = readlane64(list, i);
+    if (k == 0ull) continue;
+    const float hv = from_order_bits((unsigned)(k >> 32));
+    const unsigned idx = (unsigned)k;
+    hsum += hv;
+    i0 += (double)(idx / (unsigned)w) * (double)hv;
+    i1 += (double)(idx % (unsigned)w) * (double)hv;
+  }
+  double x = i1 / (double)hsum, y = i0 / (double)hsum;
+  if (hsum / (float)n_points <= thresh) { x = -1.0; y = -1.0; }
+  if (lane == 0) {
+    out[0] = x;
+    out[1] = y;
+  }
+}
+
 template <int MODE, int CPW>
 __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
+  if (a.gate && *a.gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [PT][LS]
   const int L = a.l, LS = L | 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
 // one wave per (face, landmark)
 template <int MODE>
 __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
+  if (a.gate && *a.gate == 0) return;
   const int lane = threadIdx.x;
   const int c = blockIdx.x, face = blockIdx.y;
   const int L = a.l;
@@ -242,23 +269,59 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
           (lane < per * a.n_points && s < a.chunks) ? part[((size_t)s * L + c) * a.n_points + rk] : 0ull;
       if (__any(cand > tau)) insert_candidates(list, tau, cand, a.n_points, lane);
     }
-    // utils/metrics.py:69-77: ascending value order = list lanes n-1 .. 0
-    float hsum = 0.f;
-    double i0 = 0.0, i1 = 0.0;
-    for (int i = a.n_points - 1; i >= 0; --i) {
-      const unsigned long long k = readlane64(list, i);
-      if (k == 0ull) continue;
-      const float hv = from_order_bits((unsigned)(k >> 32));
-      const unsigned idx = (unsigned)k;
-      hsum += hv;
-      i0 += (double)(idx / (unsigned)a.w) * (double)hv;
-      i1 += (double)(idx % (unsigned)a.w) * (double)hv;
+    if (a.tau_out) {  // threshold pass of the candidate path (flm_convt.hip): the n-th largest value, or -max
+      const unsigned long long k = readlane64(list, a.n_points - 1);
+      if (lane == 0) a.tau_out[(size_t)face * L + c] = k ? from_order_bits((unsigned)(k >> 32)) : -3.402823466e38f;
+      return;
     }
-    double x = i1 / (double)hsum, y = i0 / (double)hsum;
-    if (hsum / (float)a.n_points <= a.thresh) { x = -1.0; y = -1.0; }
-    if (lane == 0) {
-      out[0] = x;
-      out[1] = y;
+    finish_topn(list, a.n_points, a.w, a.thresh, lane, out);
+  }
+}
+
+// Exact top n of a face's candidate keys (flm_convt.hip, epilogue 3): key = order_bits(p) << 32 | class << 17 |
+// pixel.  grid = (4, faces): workgroup g owns classes 17g .. 17g+16, wave w of it the classes 17g + w + 4k; every
+// wave streams all keys of the face (L2-resident, 64 per step) and feeds the ones of its classes to the same
+// descending (value, pixel) lists as the decode of a materialised map, so ties resolve identically.
+struct CandMergeArgs {
+  const unsigned long long* cand;
+  unsigned* cand_cnt;  // [n] fill counts, [n] = fallback flag
+  int n, w, l, n_points, cap;
+  float thresh;
+  double* out;
+};
+
+constexpr int kCandClassesPerWave = 5;
+
+__global__ __launch_bounds__(256) void cand_merge_kernel(CandMergeArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int face = blockIdx.y;
+  const int cfirst = 17 * blockIdx.x, cend = min(cfirst + 17, a.l);
+  const unsigned cnt = min(a.cand_cnt[face], (unsigned)a.cap);
+  const unsigned long long* src = a.cand + (size_t)face * a.cap;
+  unsigned long long list[kCandClassesPerWave], tau[kCandClassesPerWave];
+#pragma unroll
+  for (int k = 0; k < kCandClassesPerWave; ++k) { list[k] = 0ull; tau[k] = 0ull; }
+  for (unsigned i0 = 0; i0 < cnt; i0 += 64) {
+    const unsigned long long key = (i0 + lane < cnt) ? src[i0 + lane] : 0ull;
+    const int cls = (int)((key >> 17) & 127u);
+    const unsigned long long stripped = (key & 0xffffffff00000000ull) | (key & 0x1ffffull);
+#pragma unroll
+    for (int k = 0; k < kCandClassesPerWave; ++k) {
+      const int c = cfirst + wave + 4 * k;
+      if (c < cend) {  // wave-uniform
+        const unsigned long long cand = (key != 0ull && cls == c) ? stripped : 0ull;
+        if (__any(cand > tau[k])) insert_candidates(list[k], tau[k], cand, a.n_points, lane);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kCandClassesPerWave; ++k) {
+    const int c = cfirst + wave + 4 * k;
+    if (c < cend) {
+      // fewer than n keys: the threshold did not have n pixels above it (or the class has fewer than n non-zero
+      // pixels), so the list may not hold the whole top n -> let the materialising path redo the batch
+      if (readlane64(list[k], a.n_points - 1) == 0ull && lane == 0) atomicOr(&a.cand_cnt[a.n], 1u);
+      finish_topn(list[k], a.n_points, a.w, a.thresh, lane, a.out + ((size_t)face * a.l + c) * 2);
     }
   }
 }
@@ -282,8 +345,52 @@ size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points) {
   return align_up((size_t)n * chunks * l * per, 256);
 }
 
+// tau[face][class] = n-th largest of the face's wave maxima (flm_convt.hip, epilogue 4); 0 when fewer than n are
+// non-zero (the consumer clamps to FLT_MIN and cand_merge_kernel checks that n keys arrived).
+__global__ __launch_bounds__(256) void cand_tau_kernel(const unsigned* __restrict__ wave_max, int slots, int ld, int l,
+                                                       int n_points, float* __restrict__ tau) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int face = blockIdx.x;
+  const unsigned* src = wave_max + (size_t)face * slots * ld;
+  for (int c = wave; c < l; c += 4) {
+    unsigned long long list = 0ull, t = 0ull;
+    for (int s0 = 0; s0 < slots; s0 += 64) {
+      const int sl = s0 + lane;
+      const unsigned v = sl < slots ? src[(size_t)sl * ld + c] : 0u;
+      const unsigned long long key = v ? (((unsigned long long)v << 32) | (unsigned)sl) : 0ull;
+      if (__any(key > t)) insert_candidates(list, t, key, n_points, lane);
+    }
+    const unsigned long long k = readlane64(list, n_points - 1);
+    if (lane == 0) tau[(size_t)face * l + c] = __uint_as_float((unsigned)(k >> 32));
+  }
+}
+
+int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau) {
+  if (n_points < 1 || n_points > 64 || slots < 1) {
+    set_error("cand_tau: unsupported n_points=%d slots=%d", n_points, slots);
+    return FLM_ERR_UNSUPPORTED;
+  }
+  cand_tau_kernel<<<n, 256, 0, s>>>(wave_max, slots, ld, l, n_points, tau);
+  FLM_LAUNCH_CHECK("cand_tau_kernel");
+  return FLM_OK;
+}
+
+int launch_cand_merge(hipStream_t s, const unsigned long long* cand, unsigned* cand_cnt, int n, int w, int l,
+                      int n_points, float thresh, int cap, double* out) {
+  if (l > 68 || n_points < 1 || n_points > 64) {
+    set_error("cand_merge: unsupported l=%d n_points=%d", l, n_points);
+    return FLM_ERR_UNSUPPORTED;
+  }
+  CandMergeArgs a;
+  a.cand = cand; a.cand_cnt = cand_cnt; a.n = n; a.w = w; a.l = l; a.n_points = n_points; a.cap = cap;
+  a.thresh = thresh; a.out = out;
+  cand_merge_kernel<<<dim3(4, n), 256, 0, s>>>(a);
+  FLM_LAUNCH_CHECK("cand_merge_kernel");
+  return FLM_OK;
+}
+
 int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,
-                  float thresh, double* out, void* ws, size_t ws_bytes) {
+                  float thresh, double* out, void* ws, size_t ws_bytes, float* tau_out, const unsigned* gate) {
   if (n <= 0 || h <= 0 || w <= 0 || l <= 0 || l > kMaxClasses || ld != l) {
     set_error("decode: unsupported shape n=%d h=%d w=%d l=%d (max %d landmarks)", n, h, w, l, kMaxClasses);
     return FLM_ERR_SHAPE;
@@ -312,6 +419,8 @@ int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, in
   a.hm = hm; a.n = n; a.h = h; a.w = w; a.l = l;
   decode_plan(n, h, w, &a.chunks, &a.chunk_px);
   a.mode = mode; a.n_points = n_points; a.thresh = thresh; a.part = ws; a.out = out;
+  a.tau_out = (mode == FLM_DECODE_TOPN) ? tau_out : nullptr;
+  a.gate = gate;
   a.vec = (((long long)h * w * l) & 3) == 0;
   const size_t lds = sizeof(float) * PT * (l | 1);
   dim3 grid(a.chunks, n);

@@ -1,0 +1,101 @@
+"""Landmark mode without the probability tensor (flm_convt.hip, epilogue 3) against the path that
+materialises [N,264,264,68] and decodes it: the two must agree bit for bit (float64 coordinates),
+because the candidate lists hold every pixel that can enter the top n and the final selection uses
+the same (value, flat index) keys.  Also covered: the overflow fallback (lists too small; flat maps
+where every pixel ties with the threshold) and rejected landmarks (thresh above some of the means)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def flm():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import flm_amd
+    return flm_amd
+
+
+@pytest.fixture(scope="module")
+def weights68():
+    from flm_amd.weights import synth_fcn8_weights
+    return synth_fcn8_weights(68, seed=2)
+
+
+def _knob(key, value):
+    from flm_amd import _lib
+    _lib.check(_lib.load().flm_set_tuning(key, value), "set_tuning")
+
+
+def _landmarks(model, xd, n_points, thresh, candidates, cap_div=1):
+    _knob(b"landmark_candidates", 1 if candidates else 0)
+    _knob(b"candidate_cap_div", cap_div)
+    model._ws.clear()  # the workspace layout depends on the knobs
+    try:
+        return model.forward_device(xd, "landmarks", n_points=n_points, thresh=thresh).cpu().numpy()
+    finally:
+        _knob(b"landmark_candidates", 1)
+        _knob(b"candidate_cap_div", 1)
+        model._ws.clear()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_candidate_path_equals_materialised_decode(flm, weights68, dtype):
+    from flm_amd.networks import LANDMARKS_MODELS
+    rng = np.random.default_rng(41)
+    n = 5
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
+    for n_points, thresh in ((4, 0.0), (1, 0.0), (9, 0.0), (16, 0.0), (4, 0.5)):
+        ref = _landmarks(model, xd, n_points, thresh, candidates=False)
+        got = _landmarks(model, xd, n_points, thresh, candidates=True)
+        assert got.shape == (n, 68, 2) and got.dtype == np.float64
+        assert np.array_equal(got, ref), (dtype, n_points, thresh, np.abs(got - ref).max())
+    assert (ref == -1).any() and (ref != -1).any()  # thresh 0.5 rejects part of the landmarks: both branches ran
+
+
+def test_candidate_overflow_falls_back(flm, weights68):
+    """Lists 1/4096 of their size overflow in every face: the gated materialising launch must take over."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    rng = np.random.default_rng(42)
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(rng.integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)).cuda()
+    ref = _landmarks(model, xd, 4, 0.0, candidates=False)
+    got = _landmarks(model, xd, 4, 0.0, candidates=True, cap_div=4096)
+    assert np.array_equal(got, ref)
+
+
+def test_candidate_flat_maps(flm, weights68):
+    """Zero score / upsampling kernels: every pixel has p = 1/68 exactly, all tie with the threshold, every list
+    overflows; the reference's tie rule (largest flat indices) must still come out."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from oracle import decode_ref
+    w = {k: np.array(v, copy=True) for k, v in weights68.items()}
+    for k in list(w):
+        if k.startswith(("up3", "up4", "up5")):
+            w[k][...] = 0
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+    model.load_weights(w)
+    xd = torch.from_numpy(np.random.default_rng(43).integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda()
+    ref = _landmarks(model, xd, 4, 0.0, candidates=False)
+    got = _landmarks(model, xd, 4, 0.0, candidates=True)
+    assert np.array_equal(got, ref)
+    flat = np.full((1, 264, 264, 68), np.float32(1.0) / np.float32(68.0), dtype=np.float32)
+    exp = decode_ref.transfer_target_ref(flat, 0, 4).reshape(68, 2)
+    assert np.allclose(got[0], exp, rtol=0, atol=1e-9)
+
+
+def test_candidate_path_batch_of_one_and_ragged_batch(flm, weights68):
+    from flm_amd.networks import LANDMARKS_MODELS
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+    model.load_weights(weights68)
+    rng = np.random.default_rng(44)
+    for n in (1, 7):
+        xd = torch.from_numpy(rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
+        ref = _landmarks(model, xd, 4, 0.0, candidates=False)
+        got = _landmarks(model, xd, 4, 0.0, candidates=True)
+        assert np.array_equal(got, ref), n

@@ -33,11 +33,10 @@ def run(steps=6):
 
 key = sys.argv[1]
 vals = [int(v) for v in sys.argv[2].split(",")]
-keys = None
 for v in vals:
     _lib.check(lib.flm_set_tuning(key.encode(), v), "set_tuning")
+    model._ws.clear()  # some knobs change the workspace layout
     r = run()
-    if keys is None:
-        keys = list(r.keys())
-        print("%-8s" % key[:8], " ".join("%7s" % k[:7] for k in keys), "   total")
+    keys = list(r.keys())
+    print("%-8s" % key[:8], " ".join("%7s" % k[:7] for k in keys), "   total")
     print("%-8d" % v, " ".join("%7.3f" % r[k] for k in keys), "  %7.3f" % sum(r.values()))
