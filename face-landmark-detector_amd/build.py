@@ -24,6 +24,7 @@ SOURCES = [
     "flm_enc1.hip",
     "flm_igemm.hip",
     "flm_igemm_bf16.hip",
+    "flm_conv3_halo.hip",
     "flm_convt.hip",
     "flm_decode.hip",
     "flm_misc.hip",

@@ -202,6 +202,37 @@ def test_bf16_256_row_tiles_equal_128_row_tiles(flm, weights68):
         assert np.array_equal(outs[0][0], outs[2][0])
 
 
+def test_bf16_halo_conv_equals_implicit_gemm(flm, weights68):
+    """flm_conv3_halo.hip (3x3, 64 input channels, halo + weights resident in LDS) consumes k in the implicit GEMM's
+    order: bit-identical outputs.  Vanilla enc2 exercises the pooled epilogue, VGG's block1_conv2 / block2_conv1 the
+    pooled and the un-pooled one."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_vgg_weights
+    lib = _lib.load()
+    rng = np.random.default_rng(34)
+    cases = (("fcn_8", weights68, 3, 96, 160), ("fcn_8", weights68, 2, 256, 256),
+             ("fcn_8_vgg", synth_vgg_weights(68, seed=5), 2, 64, 96))
+    for name, wts, n, h, w in cases:
+        model = LANDMARKS_MODELS[name](68, input_height=h, input_width=w, dtype="bf16")
+        model.load_weights(wts)
+        xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        outs = {}
+        try:
+            for mode in (0, 2):
+                _lib.check(lib.flm_set_tuning(b"bf16_conv3_halo", mode), "set_tuning")
+                outs[mode] = model.forward_device(xd, "probs").cpu().numpy()
+                if name == "fcn_8":
+                    outs[mode] = (outs[mode], model.intermediate("f2", n, "probs").cpu().numpy())
+        finally:
+            _lib.check(lib.flm_set_tuning(b"bf16_conv3_halo", 1), "set_tuning")
+        if name == "fcn_8":
+            assert np.array_equal(outs[0][1], outs[2][1]), (name, n, h, w, "f2")
+            assert np.array_equal(outs[0][0], outs[2][0]), (name, n, h, w)
+        else:
+            assert np.array_equal(outs[0], outs[2]), (name, n, h, w)
+
+
 def test_fcn32_forward(flm, weights68):
     """fcn_32 (networks/fcn.py:129-150): 64x64 stride-32 transposed conv, output grid H+32."""
     from flm_amd.networks import LANDMARKS_MODELS
