@@ -65,8 +65,9 @@ def load_traffic(layer):
         return None
 
 
-# decode side of the step: the landmark selection ("tau" = its threshold pass) and the gated fallback launches
-DECODE_KEYS = ("decode", "tau", "decode_fallback", "up3_fallback")
+# decode side of the step: the landmark selection ("up3_sub" + "tau" = its threshold pass over a 1/16 sample of the
+# map) and the gated fallback launches; everything else is the FCN forward whose FLOPs SURVEY 8(d) counts
+DECODE_KEYS = ("decode", "up3_sub", "tau", "decode_fallback", "up3_fallback")
 
 
 def read_profile(lib):

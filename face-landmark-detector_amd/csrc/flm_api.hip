@@ -47,15 +47,14 @@ struct ProfScope {
 };
 
 // Landmark mode without the probability tensor (flm_convt.hip): for the 68-class FCN-8 kernels, top-n decode
-// with n <= 16 (list capacities grow with n), maps below 2^17 pixels.  Default (1): bf16 only -- there the
-// probability tensor's write + re-read were 40 % of the step; the fp32 up3 is bound by the matrix pipe, writes
-// its map for free, and the sampling pass would cost what the cheaper decode saves (measured: 9.02 vs 9.17 ms
-// per 64 faces, inside run-to-run spread).  2 = on for both types, 0 = off.  Knobs for tests / A-B runs.
+// with n <= 16 (list capacities grow with n), maps below 2^17 pixels.  On by default for both types: bf16 batch
+// 512 saves the tensor's write + re-read (up3 + decode 6.2 -> 3.5 ms); fp32 batch 64 gains 1.5 % of the step (the
+// fp32 up3 is bound by the matrix pipe and writes its map for free; the gain is the decode).  0 = off (tests, A/B).
 static int g_cand_enable = 1;
 static int g_cand_cap_div = 1;  // > 1 shrinks the per-face list (tests force the overflow fallback with it)
 static int g_cand_sub = 4;      // phases per tile in the sampling launch (R of flm_convt.hip)
 static bool landmark_candidates_enabled(const ConvTGeom& g, int fcn32, int decode_mode, int n_points, int oh, int ow) {
-  return (g_cand_enable == 2 || (g_cand_enable == 1 && g.bf16)) && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 16 &&
+  return g_cand_enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 16 &&
          convt_candidates_supported(g) && (long long)oh * ow < (1 << 17);
 }
 
@@ -170,12 +169,8 @@ int flm_set_tuning(const char* key, int value) {
     flm::igemm_bf16_big_enable(value);
     return FLM_OK;
   }
-  if (!strcmp(key, "landmark_candidates")) {  // 0: always materialise the probabilities; 1: default; 2: all dtypes
-    if (value < 0 || value > 2) {
-      set_error("flm_set_tuning: landmark_candidates must be 0, 1 or 2");
-      return FLM_ERR_ARG;
-    }
-    g_cand_enable = value;
+  if (!strcmp(key, "landmark_candidates")) {  // 0: always materialise the probabilities and decode them
+    g_cand_enable = value != 0;
     return FLM_OK;
   }
   if (!strcmp(key, "candidate_sub_phases")) {

@@ -78,10 +78,23 @@ constexpr int GCH_F32 = 6, GCH_BF16 = 3;  // k groups per LDS chunk (bf16: small
 // exp(t) for t <= 0 in the softmax.  fp32 path: the accurate library expf.  bf16 path: v_exp_f32 on
 // t*log2(e) (about 1e-6 relative, far below the bf16 rounding the logits already carry); at 16x the MFMA
 // rate the 20 accurate expf per lane per phase would cost more than the phase's matrix work.
+// x: logit, mx: the pixel's maximum, nmxl = -mx * log2(e).  bf16: one fma + v_exp_f32.
 template <bool BF>
-__device__ __forceinline__ float softmax_exp(float t) {
-  if constexpr (BF) return __builtin_amdgcn_exp2f(t * 1.44269504088896340736f);
-  else return expf(t);
+__device__ __forceinline__ float softmax_exp(float x, float mx, float nmxl) {
+  if constexpr (BF) return __builtin_amdgcn_exp2f(__builtin_fmaf(x, 1.44269504088896340736f, nmxl));
+  else return expf(x - mx);
+}
+// max without the quiet-NaN canonicalisation fmaxf() drags in (two extra v_max per call on MFMA results);
+// NaN logits give NaN probabilities either way.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // MODE: 0 = epilogues 0/1/2 (maps), 1 = epilogue 3 (top-n candidates), 2 = epilogue 4 (sampling launch: wave maxima)
@@ -89,6 +102,9 @@ template <int MT, int G, bool BF, int NT, int MODE>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
   constexpr bool SAMPLE = MODE == 2;
+  // the 68-class kernels know their class count: rows 0..63 are always classes, of rows 64..79 only lane group q = 0
+  constexpr bool C68 = (MT == 5 && (G == 9 || G == 17));
+#define FLM_CVALID(M, E) (C68 ? ((M) < 4 || q == 0) : (16 * (M) + 4 * q + (E) < a.C))
   if (a.gate && *a.gate == 0) return;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr int NCH = (G + GCH - 1) / GCH;
@@ -226,25 +242,33 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   //   part 1: class maximum (in-lane + two xor-shuffles), e = exp(x - max)
   //   part 2: sum, one reciprocal, p = e * (1/sum)
   //   part 3: stores (probabilities / class map / raw + skip)
-  f32x4 pv[NT][MT];  // previous phase's accumulators, transformed in place by the parts
+  // Two accumulator sets: phase b0 accumulates into one while the parts transform the other (phase b0-1) in place.
+  f32x4 accA[NT][MT], accB[NT][MT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) pv[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) accA[nt][m] = accB[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#define FLM_EPI_PART1()                                                                           \
+#define FLM_EPI_PART1(pv)                                                                         \
   if (a.epilogue != 0) {                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
       float mx = -3.402823466e38f;                                                                \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                            \
+        const float x0 = FLM_CVALID(m, 0) ? pv[nt][m][0] : -3.402823466e38f;                      \
+        const float x1 = FLM_CVALID(m, 1) ? pv[nt][m][1] : -3.402823466e38f;                      \
+        const float x2 = FLM_CVALID(m, 2) ? pv[nt][m][2] : -3.402823466e38f;                      \
+        const float x3 = FLM_CVALID(m, 3) ? pv[nt][m][3] : -3.402823466e38f;                      \
+        mx = max3_raw(mx, x0, x1);                                                                \
+        mx = max3_raw(mx, x2, x3);                                                                \
+      }                                                                                           \
+      mx = max_raw(mx, __shfl_xor(mx, 16));                                                       \
+      mx = max_raw(mx, __shfl_xor(mx, 32));                                                       \
+      const float nmxl = -mx * 1.44269504088896340736f;                                           \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
-        if (16 * m + 4 * q + e < a.C) mx = fmaxf(mx, pv[nt][m][e]);                               \
-      mx = fmaxf(mx, __shfl_xor(mx, 16));                                                         \
-      mx = fmaxf(mx, __shfl_xor(mx, 32));                                                         \
-      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
-        pv[nt][m][e] = (16 * m + 4 * q + e < a.C) ? softmax_exp<BF>(pv[nt][m][e] - mx) : 0.f;     \
+        pv[nt][m][e] = FLM_CVALID(m, e) ? softmax_exp<BF>(pv[nt][m][e], mx, nmxl) : 0.f;          \
     }                                                                                             \
   }
-#define FLM_EPI_PART2(EPI_B0)                                                                     \
+#define FLM_EPI_PART2(pv, EPI_B0)                                                                 \
   { const int epi_b0 = (EPI_B0);                                                                   \
   if (a.epilogue != 0) {                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
@@ -263,13 +287,11 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         pv[nt][m][e] = pv[nt][m][e] * rs;                                                         \
     }                                                                                             \
   } }
-#define FLM_EPI_PART3(B0)                                                                         \
+#define FLM_EPI_PART3(pv, B0)                                                                     \
   _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                             \
     const int ph3_ = FLM_PHASE(B0);                                                               \
     const int oy = s * i0[nt] + (ph3_ >> a.ls), ox = s * j0[nt] + (ph3_ & (s - 1));                         \
     const bool ovalid = pvalid[nt] && oy < a.ho && ox < a.wo;                                     \
-    const size_t opix = a.sub ? (((size_t)img[nt] * a.sub + (B0)) * hi1 + i0[nt]) * wi1 + j0[nt]      \
-                              : ((size_t)img[nt] * a.ho + oy) * a.wo + ox;                        \
     if (SAMPLE) {                                                                                 \
       /* class maxima over the wave's 16 pixels (lanes r of one q), then one LDS max per class */  \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         v = fmaxf(v, __shfl_xor(v, 8));                                                           \
         if (r == 0) atomicMax(&wmax[16 * m + 4 * q + e], __float_as_uint(v));                      \
       }                                                                                           \
-    } else if (CAND && a.epilogue == 3) {                                                         \
+    } else if (CAND) {                                                                            \
       /* invalid pixels carry p = 0 (part 2), thresholds are >= FLT_MIN: one compare per value decides */ \
       const unsigned pixbits = (unsigned)(oy * a.wo + ox);                                        \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                            \
@@ -304,7 +326,9 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
           }                                                                                       \
         }                                                                                         \
       }                                                                                           \
-    } else if (a.epilogue == 0) {                                                                        \
+    } else {                                                                                      \
+    const size_t opix = ((size_t)img[nt] * a.ho + oy) * a.wo + ox;                                \
+    if (a.epilogue == 0) {                                                                        \
       if (ovalid) {                                                                               \
         float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;                                  \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                          \
@@ -325,13 +349,13 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         if ((a.ldy & 3) == 0) {                                                                   \
           _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                        \
             const int c4 = 16 * m + 4 * q;                                                        \
-            if (c4 < a.C)                                                                         \
+            if (FLM_CVALID(m, 0))                                                                 \
               *reinterpret_cast<float4*>(y + c4) = make_float4(pv[nt][m][0], pv[nt][m][1], pv[nt][m][2], pv[nt][m][3]); \
           }                                                                                       \
         } else {                                                                                  \
           _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
             const int c = 16 * m + 4 * q + e;                                                     \
-            if (c < a.C) y[c] = pv[nt][m][e];                                                         \
+            if (FLM_CVALID(m, e)) y[c] = pv[nt][m][e];                                            \
           }                                                                                       \
         }                                                                                         \
       }                                                                                           \
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       int bi = 0x7fffffff;                                                                        \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
         const int c = 16 * m + 4 * q + e; /* ascending within a lane */                           \
-        if (c < a.C && pv[nt][m][e] > bv) { bv = pv[nt][m][e]; bi = c; }                                  \
+        if (FLM_CVALID(m, e) && pv[nt][m][e] > bv) { bv = pv[nt][m][e]; bi = c; }                 \
       }                                                                                           \
       _Pragma("unroll") for (int sh = 16; sh <= 32; sh <<= 1) {                                   \
         const float ov = __shfl_xor(bv, sh);                                                      \
@@ -350,75 +374,70 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       }                                                                                           \
       if (ovalid && q == 0) reinterpret_cast<int*>(a.y)[opix] = bi;                               \
     }                                                                                             \
+    }                                                                                             \
   }
 
   int seq = 0;
-  for (int b0 = 0; b0 < a.nb; ++b0) {
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const bool more = seq + 1 < total;
-      if (more) FLM_ISSUE(seq + 1)
-      const float4* wl = lds + (seq & 1) * CHUNK_F4;
-      // epilogue part of the PREVIOUS phase, issued alongside this chunk's MFMAs
-      if (b0 > 0) {
-        if (ch == 0) FLM_EPI_PART1()
-        if (ch == (NCH > 1 ? 1 : 0)) FLM_EPI_PART2(b0 - 1)
-        if (ch == NCH - 1) FLM_EPI_PART3(b0 - 1)
-      }
-#pragma unroll
-      for (int gl = 0; gl < GCH; ++gl) {
-        const int g = ch * GCH + gl;  // compile-time
-        if (g < G) {
-          float4 af[MT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) af[m] = wl[(gl * MT + m) * 64 + lane];
-          if constexpr (BF) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, acc[nt][m],
-                                                                      0, 0, 0);
-            }
-          } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, acc[nt][m], 0, 0, 0);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, acc[nt][m], 0, 0, 0);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, acc[nt][m], 0, 0, 0);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, acc[nt][m], 0, 0, 0);
-            }
-          }
-        }
-      }
-      if (more) FLM_STASH((seq + 1) & 1)
-      __syncthreads();
-      ++seq;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) pv[nt][m] = acc[nt][m];
+  // One phase: MFMAs into set ACC while the three parts finish the previous phase held in set PV.
+#define FLM_PHASE_BODY(ACC, PV, B0)                                                                 \
+  {                                                                                                 \
+    const int b0 = (B0);                                                                            \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int m = 0; m < MT; ++m) \
+      ACC[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                     \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                            \
+      const bool more = seq + 1 < total;                                                            \
+      if (more) FLM_ISSUE(seq + 1)                                                                  \
+      const float4* wl = lds + (seq & 1) * CHUNK_F4;                                                \
+      if (b0 > 0) {                                                                                 \
+        if (ch == 0) FLM_EPI_PART1(PV)                                                              \
+        if (ch == (NCH > 1 ? 1 : 0)) FLM_EPI_PART2(PV, b0 - 1)                                      \
+        if (ch == NCH - 1) FLM_EPI_PART3(PV, b0 - 1)                                                \
+      }                                                                                             \
+      _Pragma("unroll") for (int gl = 0; gl < GCH; ++gl) {                                          \
+        const int g = ch * GCH + gl; /* compile-time */                                             \
+        if (g < G) {                                                                                \
+          float4 af[MT];                                                                            \
+          _Pragma("unroll") for (int m = 0; m < MT; ++m) af[m] = wl[(gl * MT + m) * 64 + lane];     \
+          if constexpr (BF) {                                                                       \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
+              const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);                              \
+              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, ACC[nt][m], 0, 0, 0); \
+            }                                                                                       \
+          } else {                                                                                  \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
+              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, ACC[nt][m], 0, 0, 0); \
+              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, ACC[nt][m], 0, 0, 0); \
+              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, ACC[nt][m], 0, 0, 0); \
+              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, ACC[nt][m], 0, 0, 0); \
+            }                                                                                       \
+          }                                                                                         \
+        }                                                                                           \
+      }                                                                                             \
+      if (more) FLM_STASH((seq + 1) & 1)                                                            \
+      __syncthreads();                                                                              \
+      ++seq;                                                                                        \
+    }                                                                                               \
   }
-  // drain: the last phase's epilogue
-  FLM_EPI_PART1()
-  FLM_EPI_PART2(a.nb - 1)
-  FLM_EPI_PART3(a.nb - 1)
+  for (int bb = 0; bb < a.nb; bb += 2) {
+    FLM_PHASE_BODY(accA, accB, bb)
+    if (bb + 1 < a.nb) FLM_PHASE_BODY(accB, accA, bb + 1)
+  }
+  // drain: the last phase's epilogue (even phase indices accumulate in set A)
+  if (a.nb & 1) {
+    FLM_EPI_PART1(accA)
+    FLM_EPI_PART2(accA, a.nb - 1)
+    FLM_EPI_PART3(accA, a.nb - 1)
+  } else {
+    FLM_EPI_PART1(accB)
+    FLM_EPI_PART2(accB, a.nb - 1)
+    FLM_EPI_PART3(accB, a.nb - 1)
+  }
+#undef FLM_PHASE_BODY
   if (SAMPLE) {
     // (same-wave LDS atomics and reads are ordered; other waves never touch this region)
     const int tiles_pf = a.ppf / (64 * NT);
@@ -445,6 +464,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 }
 
 #undef FLM_PHASE
+#undef FLM_CVALID
 #undef FLM_EPI_PART1
 #undef FLM_EPI_PART2
 #undef FLM_EPI_PART3

@@ -30,7 +30,7 @@ def _knob(key, value):
 
 
 def _landmarks(model, xd, n_points, thresh, candidates, cap_div=1):
-    _knob(b"landmark_candidates", 2 if candidates else 0)
+    _knob(b"landmark_candidates", 1 if candidates else 0)
     _knob(b"candidate_cap_div", cap_div)
     model._ws.clear()  # the workspace layout depends on the knobs
     try:

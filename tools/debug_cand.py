@@ -8,7 +8,6 @@ from flm_amd.networks import LANDMARKS_MODELS
 from flm_amd.weights import synth_fcn8_weights
 
 lib = _lib.load()
-lib.flm_set_tuning(b"landmark_candidates", 2)
 B = int(os.environ.get("B", "4")); NP = int(os.environ.get("NP", "4"))
 model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=os.environ.get("DTYPE", "f32"))
 model.load_weights(synth_fcn8_weights(68, 2))
