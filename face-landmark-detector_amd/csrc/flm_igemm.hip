@@ -262,34 +262,42 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int buf = it_ & 1, sbuf = buf ^ 1;                                                          \
     const float* Ab = As + buf * TILE_F;                                                              \
     const float* Bb = Bs + buf * TILE_F;                                                              \
-    float4 afx0, afx1, bfx0, bfx1, afy0, afy1, bfy0, bfy1;                                            \
-    FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, fc0)                                                       \
     FLM_TILE_PARAMS()                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    /* group 0: loads of A rows */                                                                    \
+    /* group 0 (fragments fetched during the previous step's group 3): global loads of tile it+2 */   \
     FLM_MFMA4(afx0, afx1, bfx0, bfx1, x) FLM_READ_FRAGS(afy0, afy1, bfy0, bfy1, fc1)                  \
-    FLM_LOAD_A(0, ra0##L, ok0##L)                                                            \
-    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y) FLM_LOAD_A(1, ra1##L, ok1##L)                       \
-    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z) FLM_LOAD_A(2, ra2##L, ok2##L)                       \
-    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w) FLM_LOAD_A(3, ra3##L, ok3##L)                       \
-    /* group 1: loads of B rows */                                                                    \
+    FLM_LOAD_A(0, ra0##L, ok0##L) FLM_LOAD_B(0, rb0##L)                                               \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y) FLM_LOAD_A(1, ra1##L, ok1##L) FLM_LOAD_B(1, rb1##L)          \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z) FLM_LOAD_A(2, ra2##L, ok2##L) FLM_LOAD_B(2, rb2##L)          \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w) FLM_LOAD_A(3, ra3##L, ok3##L) FLM_LOAD_B(3, rb3##L)          \
+    /* group 1: LDS writes of tile it+1, A rows */                                                    \
     FLM_MFMA4(afy0, afy1, bfy0, bfy1, x) FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, fc2)                  \
-    FLM_LOAD_B(0, rb0##L)                                                                    \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_LOAD_B(1, rb1##L)                               \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_LOAD_B(2, rb2##L)                               \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_LOAD_B(3, rb3##L)                               \
-    /* group 2: LDS writes of tile it+1, A rows */                                                    \
+    FLM_STORE_A(0, ra0##W, ok0##W)                                                                    \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_STORE_A(1, ra1##W, ok1##W)                               \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_STORE_A(2, ra2##W, ok2##W)                               \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_STORE_A(3, ra3##W, ok3##W)                               \
+    /* group 2: LDS writes, B rows; then the step's only barrier: every wave has fetched the fragments of */ \
+    /* group 3 by now, so this stage is dead and the next one complete */                             \
     FLM_MFMA4(afx0, afx1, bfx0, bfx1, x) FLM_READ_FRAGS(afy0, afy1, bfy0, bfy1, fc3)                  \
-    FLM_STORE_A(0, ra0##W, ok0##W)                                                           \
-    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y) FLM_STORE_A(1, ra1##W, ok1##W)                      \
-    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z) FLM_STORE_A(2, ra2##W, ok2##W)                      \
-    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w) FLM_STORE_A(3, ra3##W, ok3##W)                      \
-    /* group 3: LDS writes, B rows */                                                                 \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, x) FLM_STORE_B(0, rb0##W)                              \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_STORE_B(1, rb1##W)                              \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_STORE_B(2, rb2##W)                              \
-    FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_STORE_B(3, rb3##W)                              \
+    FLM_STORE_B(0, rb0##W)                                                                            \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y) FLM_STORE_B(1, rb1##W)                                       \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z) FLM_STORE_B(2, rb2##W)                                       \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w) FLM_STORE_B(3, rb3##W)                                       \
     __syncthreads();                                                                                  \
+    /* group 3: the next step's first fragments come from the next stage under these MFMAs: the step */ \
+    /* boundary has no barrier and no exposed LDS latency */                                          \
+    {                                                                                                 \
+      const float* Abn = As + sbuf * TILE_F;                                                          \
+      const float* Bbn = Bs + sbuf * TILE_F;                                                          \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, x)                                                            \
+      afx0 = *reinterpret_cast<const float4*>(Abn + fa0 + fc0);                                       \
+      afx1 = *reinterpret_cast<const float4*>(Abn + fa1 + fc0);                                       \
+      bfx0 = *reinterpret_cast<const float4*>(Bbn + fb0 + fc0);                                       \
+      bfx1 = *reinterpret_cast<const float4*>(Bbn + fb1 + fc0);                                       \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, y)                                                            \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, z)                                                            \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, w)                                                            \
+    }                                                                                                 \
   }
 
   // prologue: tile 0 -> set P -> LDS[0]; tile 1 -> set Q (written during step 0)
@@ -309,6 +317,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     }
   }
   __syncthreads();
+  float4 afx0, afx1, bfx0, bfx1, afy0, afy1, bfy0, bfy1;
+  afy0 = afy1 = bfy0 = bfy1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float* Ab = As;
+    const float* Bb = Bs;
+    FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, fc0)
+  }
 
   // step it writes set Q (tile it+1) and loads tile it+2 into set P; the next step swaps the roles
   for (int it = 0; it < nit; it += 2) {
