@@ -39,7 +39,13 @@ def layer_of(name, grid, batch=64):
     if "warp_kernel" in name:
         return "warp"
     if "convt_kernel" in name:
+        if name.rstrip(">(flm::ConvTArgs)").endswith(", 2") or ", 2>(" in name:
+            return "up3_sub"
         return {162: "up5", 578: "up4"}.get(g, "up3" if g > 5000 else None)
+    if "cand_merge" in name:
+        return "decode"
+    if "cand_tau" in name:
+        return "tau"
     if "igemm_kernel<false, 2" in name or "igemm_kernel<0, 2" in name or "ILb0ELi2" in name:
         return "fc6"
     if "igemm_kernel" in name and ("false, 1" in name or "ILb0ELi1" in name):
