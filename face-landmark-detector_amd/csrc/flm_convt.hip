@@ -102,9 +102,12 @@ template <int MT, int G, bool BF, int NT, int MODE>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
   constexpr bool SAMPLE = MODE == 2;
-  // the 68-class kernels know their class count: rows 0..63 are always classes, of rows 64..79 only lane group q = 0
+  // The 68-class kernels know their class count, and their packed weights put classes 64..67 on rows 0, 4, 8, 12 of
+  // the last 16-row tile (flm_pack.hip): result row 4q + e of a tile sits in register e of lane group q, so every
+  // lane holds 16 + 1 classes -- which (tile, register) slots carry a class is known at compile time.
   constexpr bool C68 = (MT == 5 && (G == 9 || G == 17));
-#define FLM_CVALID(M, E) (C68 ? ((M) < 4 || q == 0) : (16 * (M) + 4 * q + (E) < a.C))
+#define FLM_CVALID(M, E) (C68 ? ((M) < 4 || (E) == 0) : (16 * (M) + 4 * q + (E) < a.C))
+#define FLM_CLS(M, E) ((C68 && (M) == 4) ? (64 + q) : (16 * (M) + 4 * q + (E)))
   if (a.gate && *a.gate == 0) return;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr int NCH = (G + GCH - 1) / GCH;
@@ -161,8 +164,10 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   if (CAND) {
     // thresholds of this workgroup's face, clamped to FLT_MIN so that p >= tau implies p > 0 (zero weights cannot
     // move a centroid; a class left with fewer than n keys is caught by cand_merge_kernel)
-    if (tid < 16 * MT)
-      tau_s[tid] = (tid < a.C && wg_img < a.n) ? fmaxf(a.tau[(size_t)wg_img * a.C + tid], 1.17549435e-38f) : 3.402823466e38f;
+    if (tid < 16 * MT) {  // indexed by result row: class of row p
+      const int cls = (C68 && tid >= 64) ? (((tid & 3) == 0) ? 64 + ((tid - 64) >> 2) : a.C) : tid;
+      tau_s[tid] = (cls < a.C && wg_img < a.n) ? fmaxf(a.tau[(size_t)wg_img * a.C + cls], 1.17549435e-38f) : 3.402823466e38f;
+    }
   }
 
   // ---- X fragments ------------------------------------------------------------------------------------
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     const bool ovalid = pvalid[nt] && oy < a.ho && ox < a.wo;                                     \
     if (SAMPLE) {                                                                                 \
       /* class maxima over the wave's 16 pixels (lanes r of one q), then one LDS max per class */  \
-      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+       if (FLM_CVALID(m, e)) {                                                                    \
         float v = ovalid ? pv[nt][m][e] : 0.f;                                                    \
         v = fmaxf(v, __shfl_xor(v, 1));                                                           \
         v = fmaxf(v, __shfl_xor(v, 2));                                                           \
@@ -309,9 +315,9 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         const float4 tq = *reinterpret_cast<const float4*>(tau_s + 16 * m + 4 * q);               \
         unsigned long long mk[4];                                                                 \
         mk[0] = __ballot(pv[nt][m][0] >= tq.x);                                                   \
-        mk[1] = __ballot(pv[nt][m][1] >= tq.y);                                                   \
-        mk[2] = __ballot(pv[nt][m][2] >= tq.z);                                                   \
-        mk[3] = __ballot(pv[nt][m][3] >= tq.w);                                                   \
+        mk[1] = FLM_CVALID(m, 1) ? __ballot(pv[nt][m][1] >= tq.y) : 0ull;                         \
+        mk[2] = FLM_CVALID(m, 2) ? __ballot(pv[nt][m][2] >= tq.z) : 0ull;                         \
+        mk[3] = FLM_CVALID(m, 3) ? __ballot(pv[nt][m][3] >= tq.w) : 0ull;                         \
         if (mk[0] | mk[1] | mk[2] | mk[3]) { /* wave-uniform, taken for about one m in eight */   \
           _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
             if (mk[e]) {                                                                          \
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
               const unsigned slot = wcnt + rank;                                                  \
               if (((mk[e] >> lane) & 1ull) && slot < (unsigned)kCandWaveCap)                      \
                 cwave[slot] = ((unsigned long long)cand_order_bits(pv[nt][m][e]) << 32) |         \
-                              ((unsigned long long)(16 * m + 4 * q + e) << 17) | pixbits;         \
+                              ((unsigned long long)FLM_CLS(m, e) << 17) | pixbits;                \
               wcnt += __builtin_popcountll(mk[e]);                                                \
             }                                                                                     \
           }                                                                                       \
@@ -333,6 +339,12 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         float* y = reinterpret_cast<float*>(a.y) + opix * a.ldy;                                  \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                          \
           const int c4 = 16 * m + 4 * q;                                                          \
+          if (C68 && m == 4) { /* one class per lane group + the zero pad channels of the Cp-wide buffers */ \
+            float v = pv[nt][m][0];                                                               \
+            if (a.skip) v += a.skip[opix * a.Cp + 64 + q];                                        \
+            y[64 + q] = v;                                                                        \
+            if (68 + q < a.ldy) y[68 + q] = 0.f;                                                  \
+          } else                                                                                  \
           if (c4 < a.ldy) { /* ldy is a multiple of 4 here (score buffers, Cp channels) */        \
             float4 v = make_float4(pv[nt][m][0], pv[nt][m][1], pv[nt][m][2], pv[nt][m][3]);                       \
             if (a.skip) {                                                                         \
@@ -349,12 +361,13 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         if ((a.ldy & 3) == 0) {                                                                   \
           _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                        \
             const int c4 = 16 * m + 4 * q;                                                        \
-            if (FLM_CVALID(m, 0))                                                                 \
+            if (C68 && m == 4) y[64 + q] = pv[nt][m][0];                                          \
+            else if (FLM_CVALID(m, 0))                                                            \
               *reinterpret_cast<float4*>(y + c4) = make_float4(pv[nt][m][0], pv[nt][m][1], pv[nt][m][2], pv[nt][m][3]); \
           }                                                                                       \
         } else {                                                                                  \
           _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
-            const int c = 16 * m + 4 * q + e;                                                     \
+            const int c = FLM_CLS(m, e);                                                          \
             if (FLM_CVALID(m, e)) y[c] = pv[nt][m][e];                                            \
           }                                                                                       \
         }                                                                                         \
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       float bv = -1.f;                                                                            \
       int bi = 0x7fffffff;                                                                        \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
-        const int c = 16 * m + 4 * q + e; /* ascending within a lane */                           \
+        const int c = FLM_CLS(m, e); /* ascending within a lane */                                \
         if (FLM_CVALID(m, e) && pv[nt][m][e] > bv) { bv = pv[nt][m][e]; bi = c; }                 \
       }                                                                                           \
       _Pragma("unroll") for (int sh = 16; sh <= 32; sh <<= 1) {                                   \
@@ -444,7 +457,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     const int face = blockIdx.x / tiles_pf;
     unsigned* dst = reinterpret_cast<unsigned*>(a.y) + (((size_t)face * tiles_pf + tile_pf) * 4 + wave) * (16 * MT);
     if (face < a.n)
-      for (int c = lane; c < 16 * MT; c += 64) dst[c] = wmax[c];
+      for (int c = lane; c < 16 * MT; c += 64)  // class order: result row of class c
+        dst[c] = c < a.C ? wmax[(C68 && c >= 64) ? 64 + 4 * (c - 64) : c] : 0u;
   }
   if (CAND && a.epilogue == 3) {
     // flush this wave's keys to its face's list: one global atomic per wave, coalesced 8-byte stores
@@ -465,6 +479,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 
 #undef FLM_PHASE
 #undef FLM_CVALID
+#undef FLM_CLS
 #undef FLM_EPI_PART1
 #undef FLM_EPI_PART2
 #undef FLM_EPI_PART3

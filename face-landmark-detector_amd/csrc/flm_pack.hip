@@ -254,6 +254,9 @@ __global__ void pack_enc1_kernel(const float* __restrict__ src /*[3][3][3][64]*/
 // Output pixel (s*i0+a0, s*j0+b0) = sum_{di,dj in {0,1}} sum_c x[i0-di][j0-dj][c] * src[a0+s*di][b0+s*dj][o][c].
 // Fragment order: dst[phase=a0*s+b0][g][mt][lane][e], lane = (r = lane&15, q = lane>>4), EPL = 4 (fp32) or
 // 8 (bf16) elements per lane:  class o = 16*mt + r, k = 4*EPL*g + EPL*q + e, tap = k / Cp = 2*di+dj, c = k % Cp.
+// The 68-class kernels (flm_convt.hip, C68) spread classes 64..67 over the last tile's rows 0, 4, 8, 12: in the
+// MFMA result row 4q + e belongs to lane group q, so every lane then holds 17 classes (16 + one) instead of lane
+// group 0 holding 20 and the others 16 + 4 dead values.
 template <typename T>
 __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__ dst, int s, ConvTGeom g) {
   constexpr int EPL = 16 / (int)sizeof(T);
@@ -270,7 +273,8 @@ __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__
     const int mt = (int)(rem % g.MT);
     const int gg = (int)(rem / g.MT);
     const int r = lane & 15, q = lane >> 4;
-    const int o = 16 * mt + r;
+    int o = 16 * mt + r;
+    if (g.C == 68 && (g.G == 9 || g.G == 17) && mt == 4) o = (r & 3) == 0 ? 64 + (r >> 2) : g.C;  // g.C: no class
     const int k = 4 * EPL * gg + EPL * q + e;
     const int tap = k / g.Cp, c = k % g.Cp;
     float v = 0.f;
