@@ -47,14 +47,15 @@ struct ProfScope {
 };
 
 // Landmark mode without the probability tensor (flm_convt.hip): for the 68-class FCN-8 kernels, top-n decode
-// with n <= 16 (list capacities grow with n), maps below 2^17 pixels.  On by default for both types: bf16 batch
+// with n <= 32 (the threshold is the n-th of a face's 144..288 sampled maxima; list capacities grow with n), maps
+// below 2^17 pixels.  On by default for both types: bf16 batch
 // 512 saves the tensor's write + re-read (up3 + decode 6.2 -> 3.5 ms); fp32 batch 64 gains 1.5 % of the step (the
 // fp32 up3 is bound by the matrix pipe and writes its map for free; the gain is the decode).  0 = off (tests, A/B).
 static int g_cand_enable = 1;
 static int g_cand_cap_div = 1;  // > 1 shrinks the per-face list (tests force the overflow fallback with it)
 static int g_cand_sub = 4;      // phases per tile in the sampling launch (R of flm_convt.hip)
 static bool landmark_candidates_enabled(const ConvTGeom& g, int fcn32, int decode_mode, int n_points, int oh, int ow) {
-  return g_cand_enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 16 &&
+  return g_cand_enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 32 &&
          convt_candidates_supported(g) && (long long)oh * ow < (1 << 17);
 }
 
@@ -94,7 +95,7 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
     W.decode = take(cur, decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
     if (landmark_candidates_enabled(g, A.fcn32, decode_mode, n_points, W.oh, W.ow)) {
       const int h3 = h / 8, w3 = w / 8;
-      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3) * 16 * g.MT);  // wave maxima
+      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, g_cand_sub) * 16 * g.MT);  // sampled maxima
       W.tau = take(cur, sizeof(float) * (size_t)n * C);
       // expected keys per class: the n-th of 1/64 of the pixels ranks about 64*n-th overall; x4 head room
       W.cand_cap = (int)align_up((size_t)C * 64 * n_points * 4 / g_cand_cap_div, 64);
@@ -528,7 +529,7 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     rc = launch_convt(s, ts); }
     if (rc) return rc;
     { ProfScope ps(s, "tau");
-    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi), 16 * L.g.MT, C,
+    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, g_cand_sub), 16 * L.g.MT, C,
                          n_points, tau); }
     if (rc) return rc;
     ConvTDesc tc = t;

@@ -27,8 +27,8 @@
 //   1. a sampling launch computes R of the 64 phases per tile of input positions (R/64 of the work; which
 //      phases is a fixed function of the tile index, spread over all 64: the phases are separate filters, so
 //      a sample from one phase alone is not representative of the map).  It writes no map either: every
-//      wave keeps the per-class maximum of its 16*NT*R sampled pixels (epilogue 4), and cand_tau_kernel
-//      (flm_decode.hip) takes tau[face][class] = the n-th largest of the face's 36..72 wave maxima.  Those
+//      wave keeps the per-class maximum of its 16*NT pixels of every sampled phase (epilogue 4), and
+//      cand_tau_kernel (flm_decode.hip) takes tau[face][class] = the n-th largest of the face's 144..288 maxima.  Those
 //      are values of n distinct pixels of the full map, so at least n pixels are >= tau and every member of
 //      the true top n is;
 //   2. the full launch keeps its probabilities in registers and appends (value, class, pixel) keys of the
@@ -66,7 +66,8 @@ struct ConvTArgs {
   const unsigned* gate;       // non-null: the launch does nothing unless *gate != 0
 };
 
-constexpr int kCandWaveCap = 512;  // candidate keys one wave can hold in LDS (256 pixels x 68 classes pass through it)
+constexpr int kCandWaveCap = 1024;  // candidate keys one wave can hold in LDS (128 or 256 pixels x 68 classes pass through it)
+constexpr int kMaxSamplePhases = 16;
 
 __device__ __forceinline__ unsigned cand_order_bits(float v) {
   const unsigned u = __float_as_uint(v);
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   // sampling launch (epilogue 4): per-wave class maxima as float bit patterns (p >= 0: unsigned order = float order)
   unsigned* wmax = reinterpret_cast<unsigned*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 +
                                                (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0)) +
-                   wave * 16 * MT;
+                   wave * kMaxSamplePhases * 16 * MT;  // [phase of the tile's list][result row]
   if (SAMPLE)
-    for (int c = lane; c < 16 * MT; c += 64) wmax[c] = 0u;
+    for (int c = lane; c < a.sub * 16 * MT; c += 64) wmax[c] = 0u;
 
   const int s = a.s;
   // Phase (a0, b0) of iteration IT of this workgroup: phase row blockIdx.y, b0 = IT; in the sampling launch the
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         v = fmaxf(v, __shfl_xor(v, 2));                                                           \
         v = fmaxf(v, __shfl_xor(v, 4));                                                           \
         v = fmaxf(v, __shfl_xor(v, 8));                                                           \
-        if (r == 0) atomicMax(&wmax[16 * m + 4 * q + e], __float_as_uint(v));                      \
+        if (r == 0) atomicMax(&wmax[(B0) * 16 * MT + 16 * m + 4 * q + e], __float_as_uint(v));     \
       }                                                                                           \
     } else if (CAND) {                                                                            \
       /* invalid pixels carry p = 0 (part 2), thresholds are >= FLT_MIN: one compare per value decides */ \
@@ -455,10 +456,13 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     // (same-wave LDS atomics and reads are ordered; other waves never touch this region)
     const int tiles_pf = a.ppf / (64 * NT);
     const int face = blockIdx.x / tiles_pf;
-    unsigned* dst = reinterpret_cast<unsigned*>(a.y) + (((size_t)face * tiles_pf + tile_pf) * 4 + wave) * (16 * MT);
+    // one slot of 16*MT values per (wave, sampled phase), in class order
+    unsigned* dst = reinterpret_cast<unsigned*>(a.y) + (((size_t)face * tiles_pf + tile_pf) * 4 + wave) * a.sub * (16 * MT);
     if (face < a.n)
-      for (int c = lane; c < 16 * MT; c += 64)  // class order: result row of class c
-        dst[c] = c < a.C ? wmax[(C68 && c >= 64) ? 64 + 4 * (c - 64) : c] : 0u;
+      for (int i = lane; i < a.sub * 16 * MT; i += 64) {
+        const int it = i / (16 * MT), c = i % (16 * MT);
+        dst[i] = c < a.C ? wmax[it * 16 * MT + ((C68 && c >= 64) ? 64 + 4 * (c - 64) : c)] : 0u;
+      }
   }
   if (CAND && a.epilogue == 3) {
     // flush this wave's keys to its face's list: one global atomic per wave, coalesced 8-byte stores
@@ -494,7 +498,7 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64 + (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0) +
-                         sizeof(unsigned) * 4 * 16 * MT;
+                         (MODE == 2 ? sizeof(unsigned) * 4 * kMaxSamplePhases * 16 * MT : 0);
   static bool attr_done = false;
   if (!attr_done) {
     FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT, MODE>),
@@ -512,10 +516,11 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
   return FLM_OK;
 }
 
-// Wave maxima written by the sampling launch per face (epilogue 4): 4 waves per tile of 64*NT positions.
-int convt_sample_slots(const ConvTGeom& g, int hi, int wi) {
+// Maxima written by the sampling launch per face (epilogue 4): one per wave (4 per tile of 64*NT positions) and
+// sampled phase.
+int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub) {
   const int nt = g.bf16 ? 2 : 1;
-  return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt);
+  return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt) * sub;
 }
 
 int convt_candidates_supported(const ConvTGeom& g) {
@@ -554,7 +559,7 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     return d.g.bf16 ? launch_t<5, 9, true, 2, 1>(st, a) : launch_t<5, 17, false, 1, 1>(st, a);
   }
   if (d.epilogue == 4) {
-    if (!convt_candidates_supported(d.g) || !d.sub || !d.y) {
+    if (!convt_candidates_supported(d.g) || d.sub < 1 || d.sub > kMaxSamplePhases || !d.y) {
       set_error("convt: the sampling epilogue needs the 68-class kernels, sub > 0 and an output buffer");
       return FLM_ERR_UNSUPPORTED;
     }

@@ -49,7 +49,7 @@ def test_candidate_path_equals_materialised_decode(flm, weights68, dtype):
     model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
     model.load_weights(weights68)
     xd = torch.from_numpy(rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
-    for n_points, thresh in ((4, 0.0), (1, 0.0), (9, 0.0), (16, 0.0), (4, 0.5)):
+    for n_points, thresh in ((1, 0.0), (9, 0.0), (25, 0.0), (32, 0.0), (4, 0.0), (4, 0.5)):
         ref = _landmarks(model, xd, n_points, thresh, candidates=False)
         got = _landmarks(model, xd, n_points, thresh, candidates=True)
         assert got.shape == (n, 68, 2) and got.dtype == np.float64
