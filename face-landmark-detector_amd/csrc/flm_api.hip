@@ -82,7 +82,14 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   W.score5 = take(cur, sizeof(float) * (size_t)n * h5 * w5 * g.Cp);
   W.fuse4 = take(cur, sizeof(float) * (size_t)n * h4 * w4 * g.Cp);
   W.seg = take(cur, sizeof(float) * (size_t)n * h3 * w3 * g.Cp);
+  // split-K partial sums: the score convs (8 slices of [n*h5*w5][Cp]) and fc6 / fc7 while they have at most 64
+  // tiles (8 slices of [<= 256 rows][4096])
   W.splitk_bytes = sizeof(float) * 8 * (size_t)n * h5 * w5 * g.Cp;
+  {
+    const size_t rows = (size_t)n * h5 * w5 < 256 ? (size_t)n * h5 * w5 : 256;
+    const size_t fc_bytes = sizeof(float) * 8 * rows * kFc;
+    if (fc_bytes > W.splitk_bytes) W.splitk_bytes = fc_bytes;
+  }
   W.splitk = take(cur, W.splitk_bytes);
   W.oh = h + (A.fcn32 ? 32 : 8);  // (h/32 - 1)*32 + 64 (fcn.py:145) vs (h/8 - 1)*8 + 16 (fcn.py:121)
   W.ow = w + (A.fcn32 ? 32 : 8);
@@ -456,10 +463,12 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   const int h5 = h / 32, w5 = w / 32, h4 = h / 16, w4 = w / 16, h3 = h / 8, w3 = w / 8;
   // head (fcn.py:98-103); Dropout is the identity at inference
   { ProfScope ps(s, "fc6");
-  rc = conv_layer(s, blob, L.fc6, f[4], fc6, n, h5, w5, 1, 0, /*posmajor*/ 1, dtype); }
+  rc = conv_layer(s, blob, L.fc6, f[4], fc6, n, h5, w5, 1, 0, /*posmajor*/ 1, dtype, 0,
+                  reinterpret_cast<float*>(ws + W.splitk), W.splitk_bytes); }
   if (rc) return rc;
   { ProfScope ps(s, "fc7");
-  rc = conv_layer(s, blob, L.fc7, fc6, fc7, n, h5, w5, 1, 0, 0, dtype); }
+  rc = conv_layer(s, blob, L.fc7, fc6, fc7, n, h5, w5, 1, 0, 0, dtype, 0,
+                  reinterpret_cast<float*>(ws + W.splitk), W.splitk_bytes); }
   if (rc) return rc;
   { ProfScope ps(s, "score5");
   rc = conv_layer(s, blob, L.score5, fc7, score5, n, h5, w5, 0, 0, 0, dtype, /*out_f32*/ 1,

@@ -378,8 +378,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float u = fmaf(acc[i][j][r], sc, sh);
-          if (a.ksplit > 1) {
-            if (cok && m < a.M) a.part[((size_t)blockIdx.y * a.M + m) * a.ldc + col] = acc[i][j][r];
+          if (a.ksplit > 1) {  // raw partial sums, stored in output row order
+            if (cok && m < a.M) {
+              const size_t prow = (MMAP == 2) ? (size_t)(m % a.n) * (a.h * a.w) + m / a.n : (size_t)m;
+              a.part[((size_t)blockIdx.y * a.M + prow) * a.ldc + col] = acc[i][j][r];
+            }
             continue;
           }
           if (cok && m < a.M) {
@@ -423,8 +426,8 @@ static int launch_t(hipStream_t s, const IgemmArgs& a) {
 
 // y[m][c] = act(scale[c] * sum_s part[s][m][c] + shift[c]); fixed summation order (deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, float* __restrict__ y, int M, int ldc, int cout,
-                                     int ksplit, int relu) {
+                                     const float* __restrict__ shift, void* __restrict__ y, int M, int ldc, int cout,
+                                     int ksplit, int relu, int out_bf16) {
   const size_t total = (size_t)M * ldc;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % ldc);
@@ -433,7 +436,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
     for (int s = 0; s < ksplit; ++s) v += part[(size_t)s * total + i];
     v = fmaf(v, scale[c], shift[c]);
     if (relu) v = fmaxf(v, 0.f);
-    y[i] = v;
+    if (out_bf16) reinterpret_cast<unsigned short*>(y)[i] = f2bf(v);
+    else reinterpret_cast<float*>(y)[i] = v;
   }
 }
 
@@ -496,16 +500,19 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   a.mtiles = cdiv(a.M, BM);
   a.cpt = d.cin / bke;
   a.kw_magic = (65536 + d.kw - 1) / d.kw;
-  // split-K for 1x1 layers whose tile grid cannot fill the chip (score5: 32 workgroups at batch 64)
+  // split-K (over the channel chunks of every tap) for layers whose tile grid cannot fill the chip: score5
+  // (32 workgroups at batch 64), fc6 / fc7 at batches of a few faces (32 workgroups walk 205 MB of weights)
   a.ksplit = 1;
   a.gm = a.gn = 1;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
-  if (d.splitk_ws && d.kh * d.kw == 1 && !d.pool && !d.posmajor && !d.res && tiles <= 64 && a.cpt >= 32 &&
-      (!d.bf16 || d.out_f32)) {
-    int ks = 256 / tiles;
-    if (ks > 8) ks = 8;
-    if (ks > a.cpt / 8) ks = a.cpt / 8;
+  // The slice count depends on the layer only, not on the batch: every batch that is split at all (<= 64 tiles:
+  // up to 4 faces for fc6 / fc7) sums in the same order, so a face's result does not depend on its neighbours.
+  if (d.splitk_ws && !d.pool && !d.res && stride == 1 && tiles <= 64 &&
+      (d.kh * d.kw == 1 ? a.cpt >= 32 : a.cpt >= 4) && d.relu != 2) {
+    int ks = 8;
+    const int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
+    if (ks > a.cpt / per) ks = a.cpt / per;
     if (ks > 1 && (size_t)ks * a.M * d.ldc * sizeof(float) <= d.splitk_ws_bytes) {
       a.ksplit = ks;
       a.part = d.splitk_ws;
@@ -525,8 +532,8 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   if (rc || a.ksplit <= 1) return rc;
   const size_t total = (size_t)a.M * d.ldc;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, reinterpret_cast<float*>(a.y), a.M, d.ldc,
-                                              d.cout, a.ksplit, d.relu);
+  splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, a.y, a.M, d.ldc, d.cout, a.ksplit, d.relu,
+                                              d.bf16 && !d.out_f32);
   FLM_LAUNCH_CHECK("splitk_reduce_kernel");
   return FLM_OK;
 }
