@@ -184,7 +184,19 @@ int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* 
  * returns its layer name and duration in ms; it returns 1 past the last record.
  * Process-global, not thread-safe: a measurement aid, off by default. */
 int flm_profile_enable(int max_records);
-/* Performance knobs (never change results); key "none" is always accepted, unknown keys fail. */
+/* Performance knobs (never change results); key "none" is always accepted, unknown keys fail.  Process-global,
+ * read at launch time; meant for A/B runs (tools/tune.py) and for tests that force a code path:
+ *   "bf16_big_tiles"        0 off | 1 auto (default) | 2 whenever the shape allows | 3 auto + 256x128 tiles
+ *                           256-row bf16 implicit-GEMM tiles (csrc/flm_igemm_bf16.hip)
+ *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
+ *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
+ *   "landmark_candidates"   0: FLM_OUT_LANDMARKS always materialises the probabilities and decodes them;
+ *                           1 (default): top-n with n <= 32 on the 68-class FCN-8 kernels selects from candidate
+ *                           keys emitted by the last transposed conv (bit-identical results, gated fallback)
+ *   "candidate_sub_phases"  phases per tile in that path's sampling launch (1..16, default 4)
+ *   "candidate_cap_div"     shrink the candidate lists by this factor (tests of the overflow fallback)
+ * "landmark_candidates" and "candidate_*" change the workspace layout: query flm_*_workspace_bytes after
+ * setting them. */
 int flm_set_tuning(const char* key, int value);
 /* Diagnostics for developers ("igemm_occupancy", arg = dynamic LDS bytes -> workgroups per CU). */
 int flm_debug_query(const char* key, int arg);

@@ -49,6 +49,36 @@ def test_size_queries_answer_without_a_gpu():
     assert lib.flm_decode_workspace_bytes(2, 264, 264, 68, _lib.DECODE_TOPN, 4) > 0
 
 
+def test_tuning_knobs_and_workspace_layout():
+    """flm_set_tuning: documented keys are accepted, unknown keys and bad values fail with a message; the candidate
+    landmark path (flm.h) adds its lists to the workspace only where it applies (top-n <= 32, 68 classes, fcn_8)."""
+    from flm_amd import _lib
+    lib = _lib.load()
+    for key, val in ((b"none", 0), (b"bf16_big_tiles", 1), (b"bf16_group_n", 0), (b"bf16_conv3_halo", 1),
+                     (b"landmark_candidates", 1), (b"candidate_sub_phases", 4), (b"candidate_cap_div", 1)):
+        assert lib.flm_set_tuning(key, val) == 0, key
+    assert lib.flm_set_tuning(b"no_such_knob", 1) != 0 and b"no_such_knob" in lib.flm_last_error()
+    assert lib.flm_set_tuning(b"bf16_group_n", 3) != 0
+    assert lib.flm_set_tuning(b"candidate_sub_phases", 0) != 0
+    assert lib.flm_set_tuning(b"candidate_cap_div", 0) != 0
+    args = (8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN)
+    try:
+        on = lib.flm_fcn8_workspace_bytes(*args, 4)
+        assert lib.flm_set_tuning(b"landmark_candidates", 0) == 0
+        off = lib.flm_fcn8_workspace_bytes(*args, 4)
+        assert on > off > 0
+        assert lib.flm_set_tuning(b"landmark_candidates", 1) == 0
+        assert lib.flm_fcn8_workspace_bytes(*args, 64) == lib.flm_fcn8_workspace_bytes(*args, 64)  # n > 32: no lists
+        big_n = lib.flm_fcn8_workspace_bytes(*args, 64)
+        lib.flm_set_tuning(b"landmark_candidates", 0)
+        assert big_n == lib.flm_fcn8_workspace_bytes(*args, 64)
+        lib.flm_set_tuning(b"landmark_candidates", 1)
+        # all-pixel mode and other class counts keep the materialised path
+        assert lib.flm_fcn8_workspace_bytes(8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_ALL, 0) < on
+    finally:
+        lib.flm_set_tuning(b"landmark_candidates", 1)
+
+
 def test_null_arguments_are_rejected_not_dereferenced():
     lib = _lib.load()
     assert lib.flm_decode(None, None, 1, 8, 8, 1, 0, 0, 0.0, None, None, 0) == -1
