@@ -179,8 +179,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   // global loads of tile t+2 into one register set and writes tile t+1 (loaded during step t-1, so long
   // landed) from the other set into LDS[(t+1)&1].  Every non-matrix instruction sits in the shadow of an
   // MFMA (one 64-cycle MFMA holds the SIMD's issue port for a few cycles only), the wave never waits on
-  // memory it asked for less than a full step ago, and the only exposed window per step is the barrier
-  // plus the first fragment read.  Register sets are NAMED scalars (arrays under `if` go to scratch).
+  // memory it asked for less than a full step ago.  The step's one barrier sits after fragment group 2, when the
+  // writes of tile t+1 are done and every wave has fetched its last fragments of tile t; group 3 then reads the
+  // next step's first fragments from the other stage, so the step boundary itself has neither a barrier nor an
+  // exposed LDS read (measured neutral next to a barrier at the step end: two co-resident workgroups already
+  // cover each other).  Register sets are NAMED scalars (arrays under `if` go to scratch).
   float4 ra0P, ra1P, ra2P, ra3P, rb0P, rb1P, rb2P, rb3P;
   float4 ra0Q, ra1Q, ra2Q, ra3Q, rb0Q, rb1Q, rb2Q, rb3Q;
   bool ok0P = false, ok1P = false, ok2P = false, ok3P = false;
