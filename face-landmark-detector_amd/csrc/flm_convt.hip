@@ -66,7 +66,9 @@ struct ConvTArgs {
   const unsigned* gate;       // non-null: the launch does nothing unless *gate != 0
 };
 
-constexpr int kCandWaveCap = 1024;  // candidate keys one wave can hold in LDS (128 or 256 pixels x 68 classes pass through it)
+// candidate keys one wave can hold in LDS: 128 (fp32) or 256 (bf16, NT = 2) pixels x 68 classes pass through it;
+// the fp32 kernel's 61 KiB weight ring leaves room for 512 per wave if two workgroups are to share a CU
+#define kCandWaveCap (512 * NT)
 constexpr int kMaxSamplePhases = 16;
 
 __device__ __forceinline__ unsigned cand_order_bits(float v) {
@@ -499,6 +501,9 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64 + (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0) +
                          (MODE == 2 ? sizeof(unsigned) * 4 * kMaxSamplePhases * 16 * MT : 0);
+  // two workgroups per CU (160 KiB of LDS) is what the 68-class kernels are scheduled for: a key buffer that pushed the
+  // fp32 candidate kernel to 94 KiB cost 22 % of up3
+  static_assert(!(MT == 5 && (G == 9 || G == 17)) || MODE == 2 || lds <= 80 * 1024, "convt: LDS budget of two workgroups per CU");
   static bool attr_done = false;
   if (!attr_done) {
     FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT, MODE>),
