@@ -24,7 +24,7 @@ EXPORTS = [
     "flm_fcn32_packed_bytes", "flm_fcn32_pack", "flm_fcn32_workspace_bytes", "flm_fcn32_forward",
     "flm_fcn_packed_bytes", "flm_fcn_pack", "flm_fcn_workspace_bytes", "flm_fcn_forward",
     "flm_fcn8_workspace_bytes", "flm_fcn8_forward", "flm_fcn8_workspace_offset", "flm_fcn8_run_layer",
-    "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
+    "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_filter", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
     "flm_decode_workspace_bytes", "flm_decode",
     "flm_similarity_from_landmarks", "flm_warp_affine", "flm_crop_resize",
@@ -91,6 +91,8 @@ def _declare(lib):
     lib.flm_fcn8_workspace_offset.argtypes = [C.c_char_p] + [i] * 8
     lib.flm_fcn8_run_layer.restype = i
     lib.flm_fcn8_run_layer.argtypes = [vp, vp, C.c_char_p, vp, vp, i, i, i, i, i]
+    lib.flm_profile_filter.restype = i
+    lib.flm_profile_filter.argtypes = [C.c_char_p]
     lib.flm_set_tuning.restype = i
     lib.flm_set_tuning.argtypes = [C.c_char_p, i]
     lib.flm_debug_query.restype = i

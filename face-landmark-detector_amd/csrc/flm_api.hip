@@ -30,12 +30,13 @@ struct ProfRec {
 };
 static ProfRec* g_prof = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
+static char g_prof_filter[32] = "";  // non-empty: only launches of this layer are bracketed
 
 struct ProfScope {
   hipStream_t s;
   ProfRec* r;
   ProfScope(hipStream_t st, const char* name) : s(st), r(nullptr) {
-    if (g_prof && g_prof_n < g_prof_cap) {
+    if (g_prof && g_prof_n < g_prof_cap && (!g_prof_filter[0] || !strcmp(g_prof_filter, name))) {
       r = &g_prof[g_prof_n++];
       r->name = name;
       (void)hipEventRecord(r->a, s);
@@ -255,6 +256,14 @@ int flm_profile_disable(void) {
   delete[] g_prof;
   g_prof = nullptr;
   g_prof_cap = g_prof_n = 0;
+  return FLM_OK;
+}
+int flm_profile_filter(const char* layer) {
+  if (layer && strlen(layer) >= sizeof(g_prof_filter)) {
+    set_error("flm_profile_filter: layer name too long");
+    return FLM_ERR_ARG;
+  }
+  strcpy(g_prof_filter, layer ? layer : "");
   return FLM_OK;
 }
 const char* flm_last_error(void) { return g_err; }

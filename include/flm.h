@@ -184,6 +184,9 @@ int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* 
  * returns its layer name and duration in ms; it returns 1 past the last record.
  * Process-global, not thread-safe: a measurement aid, off by default. */
 int flm_profile_enable(int max_records);
+/* Bracket only the launches of one layer ("fc6", ...; NULL or "" = every launch).  Every event pair costs a few
+ * microseconds of stream time, so a timed region that only needs the dominant kernel's duration filters on it. */
+int flm_profile_filter(const char* layer);
 /* Performance knobs (never change results); key "none" is always accepted, unknown keys fail.  Process-global,
  * read at launch time; meant for A/B runs (tools/tune.py) and for tests that force a code path:
  *   "bf16_big_tiles"        0 off | 1 auto (default) | 2 whenever the shape allows | 3 auto + 256x128 tiles
