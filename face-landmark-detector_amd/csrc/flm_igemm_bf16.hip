@@ -390,6 +390,8 @@ static int dispatch_big(hipStream_t s, const IgemmArgs& a, int relu, int pool, i
 
 int launch_igemm_bf16_big(hipStream_t s, const IgemmArgs& a, int relu, int pool, int posmajor, int coutpad) {
   if (!g_big_enable || a.ksplit > 1 || a.stride != 1 || a.res) return 0;
+  // buffer offsets at or above 0x80000000 mean "zero padding" here: operands must stay below 2 GiB
+  if ((long long)a.n * a.h * a.w * a.cin * 2 + (1 << 20) >= (1ll << 31) || (long long)coutpad * a.K * 2 >= (1ll << 31)) return 0;
   // 256-wide N tiles need whole 256-row weight panels; 128-channel layers take the 256x128 shape
   const bool wide = (coutpad % 256 == 0) && a.cout > 128;
   const int bn = wide ? 256 : 128;
