@@ -99,3 +99,19 @@ def test_candidate_path_batch_of_one_and_ragged_batch(flm, weights68):
         ref = _landmarks(model, xd, 4, 0.0, candidates=False)
         got = _landmarks(model, xd, 4, 0.0, candidates=True)
         assert np.array_equal(got, ref), n
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_candidate_path_on_a_non_square_input(flm, weights68, dtype):
+    """96x160 crops -> 104x168 maps: 13x21 input positions per face do not fill the position tiles, faces are padded
+    per workgroup, and the sampled phases come from partly empty tiles."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    rng = np.random.default_rng(45)
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=96, input_width=160, dtype=dtype)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(rng.integers(0, 256, (3, 96, 160, 3), dtype=np.uint8)).cuda()
+    for n_points in (4, 12):
+        ref = _landmarks(model, xd, n_points, 0.0, candidates=False)
+        got = _landmarks(model, xd, n_points, 0.0, candidates=True)
+        assert np.array_equal(got, ref), (dtype, n_points)
+    assert ref[..., 0].max() < 168 and ref[..., 1].max() < 104
