@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 
   // ---- weight stream: (b0, chunk) sequence for this phase row ------------------------------------
   const size_t phase_f4 = (size_t)G * MT * 64;
-  const float4* wbase = reinterpret_cast<const float4*>(a.wf);
+  // raw buffer loads: per-thread offset tid*16 is a constant VGPR, phase / chunk / 4 KiB-step ride in the scalar
+  // offset (no vector address arithmetic per load); reads past the packed array return zeros
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.wf), 0, (int)((size_t)s * s * phase_f4 * 16 < 0x7fffffffull ? (size_t)s * s * phase_f4 * 16 : 0x7fffffffull),
+      0x00020000);
+  const unsigned wvoff = (unsigned)tid * 16u;
   const int total = a.nb * NCH;
   // Staging registers are NAMED scalars: an indexed array here (even fully unrolled) is left in scratch
   // memory by hipcc when it is written and read under separate `if (more)` branches.
@@ -215,10 +220,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   float4 st0, st1, st2, st3, st4, st5, st6, st7, st8;
 #define FLM_FOR_ST(X) X(0, st0) X(1, st1) X(2, st2) X(3, st3) X(4, st4) X(5, st5) X(6, st6) X(7, st7) X(8, st8)
 #define FLM_LD1(I, R)                                \
-  if constexpr (I < NLD) {                           \
-    const int idx = tid + 256 * I;                   \
-    R = src_[idx < cnt_ ? idx : 0];                  \
-  }
+  if constexpr (I < NLD)                             \
+    R = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrd, wvoff, soff_ + 4096 * I, 0));
 #define FLM_ST1(I, R)                                \
   if constexpr (I < NLD) {                           \
     const int idx = tid + 256 * I;                   \
@@ -228,9 +231,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   {                                                                                     \
     const int sq_ = (SEQ);                                                              \
     const int b0_ = sq_ / NCH, ch_ = sq_ % NCH;                                         \
-    const int ng_ = (G - ch_ * GCH) < GCH ? (G - ch_ * GCH) : GCH;                      \
-    const int cnt_ = ng_ * MT * 64;                                                     \
-    const float4* src_ = wbase + (size_t)FLM_PHASE(b0_) * phase_f4 + (size_t)ch_ * CHUNK_F4; \
+    /* (the last chunk of a phase is shorter: its tail reads the next phase's first groups, never used) */ \
+    const int soff_ = (int)(((size_t)FLM_PHASE(b0_) * phase_f4 + (size_t)ch_ * CHUNK_F4) * 16);  \
     FLM_FOR_ST(FLM_LD1)                                                                 \
   }
 #define FLM_STASH(BUF)                                                                  \
