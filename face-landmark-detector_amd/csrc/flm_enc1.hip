@@ -5,34 +5,38 @@
 //   mean cannot be folded into the bias; Conv2D(64,3x3) + BatchNormalization + ReLU + MaxPool 2x2
 //   (networks/fcn.py:26-30).
 //
-// One 256-thread workgroup handles one pooled output row of one face: per strip of 32 pooled
-// pixels (64 input columns x 2 input rows = 128 conv outputs) it stages the 4 x 66 x 3 input halo
-// in LDS as preprocessed fp32, builds the im2col fragments straight from the halo (K = 27 padded
-// to 32) and runs 32 v_mfma_f32_32x32x2_f32 per wave; BN/ReLU/pool happen on the accumulator
-// (the 2x2 window is registers 4j..4j+3 of a lane).  The 64x32 filter matrix lives in registers.
+// fp32 (enc1_kernel) and bf16 (enc1_bf16_kernel) variants below share the scheme: a workgroup owns a few pooled
+// output rows of one face, stages the 4-row input halo of a pooled row once in LDS (preprocess fused), and
+// every strip of 32 pooled pixels (64 input columns x 2 rows = 128 conv outputs) reads its im2col fragments
+// straight from the halo; BN/ReLU/pool happen on the accumulator (the 2x2 window is registers 4j..4j+3 of a
+// lane).  The filter matrix lives in registers.
 #include "flm_common.h"
 
 namespace flm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int HALO_W = 66;              // 64 columns + 1 each side
-constexpr int HALO_STRIDE = 208;        // floats per halo row: 198 used; 208 = 16 (mod 32) keeps the two
-                                        // image rows of a lane group on disjoint LDS banks
-constexpr int HALO_F = 4 * HALO_STRIDE;
+// One 256-thread workgroup handles kEnc1RowsPerWgF32 pooled output rows of one face.  Per pooled row the whole
+// 4-row input halo (4 x (w+2) x 3) is staged once in LDS as preprocessed fp32 (12 bytes = 3 aligned dwords per
+// thread and step when the input is uint8), then every strip of 32 pooled pixels builds its im2col fragments
+// straight from the halo (K = 27 padded to 32) and runs 32 v_mfma_f32_32x32x2_f32 per wave.
+constexpr int kEnc1RowsPerWgF32 = 2;
 
-__device__ __forceinline__ int koff_of(int k) {  // halo offset of patch element k = ky*9 + kx*3 + c
-  return (k < 27) ? (k / 9) * HALO_STRIDE + (k % 9) : -1;
+__host__ __device__ inline int enc1_halo_stride(int w) {  // floats per halo row: = 16 (mod 32) keeps the two image rows
+  const int need = (((w / 2 + 31) / 32) * 64 + 2) * 3;     // of a lane group on disjoint LDS banks
+  return need + ((16 - need % 32) + 32) % 32;
 }
 
 template <bool U8, bool OBF, bool POOL>
 __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin, const float* __restrict__ w1p,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    void* __restrict__ f1, int n, int h, int w) {
-  __shared__ __attribute__((aligned(16))) float halo[HALO_F];
+  extern __shared__ __attribute__((aligned(16))) float halo[];  // [4][hs]
+  const int hs = enc1_halo_stride(w);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hp = h >> 1, wp = w >> 1;
-  const int img = blockIdx.x / hp, yp = blockIdx.x % hp;
+  const int rgroups = (hp + kEnc1RowsPerWgF32 - 1) / kEnc1RowsPerWgF32;
+  const int img = blockIdx.x / rgroups, yp_first = (blockIdx.x % rgroups) * kEnc1RowsPerWgF32;
   const int lr = lane & 31, lh = lane >> 5;
 
   // filter fragments: B[k][o] with o = 32*j + lr, k = 8t + 4*lh + e
@@ -49,90 +53,117 @@ __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin,
     sh[j] = shift[32 * j + lr];
   }
 
-  // this lane's conv-output pixel inside the strip: row r = 32*wave + lr -> quad q, (dy,dx)
+  // this lane's conv-output pixel inside a strip: row r = 32*wave + lr -> quad q, (dy,dx)
   const int r = 32 * wave + lr;
   const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
-  const int pbase = dy * HALO_STRIDE + (2 * q + dx) * 3;
-
   const float mean_rgb[3] = {123.68f, 116.779f, 103.939f};  // means of B,G,R reversed to R,G,B order
 
-  for (int xp0 = 0; xp0 < wp; xp0 += 32) {
-    __syncthreads();  // previous strip's fragment reads are done
-    // ---- stage halo: rows 2yp-1..2yp+2, cols 2xp0-1..2xp0+64, 3 channels, preprocessed ----------
-    for (int e = tid; e < 4 * HALO_W * 3; e += 256) {
-      const int hr = e / (HALO_W * 3), rest = e % (HALO_W * 3);
-      const int hc = rest / 3, ch = rest % 3;
-      const int iy = 2 * yp - 1 + hr, ix = 2 * xp0 - 1 + hc;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) {
-        const size_t pix = ((size_t)img * h + iy) * w + ix;
-        if (U8) {
-          // output channel ch (RGB order) = input channel 2-ch (BGR) minus that channel's mean
-          v = (float)reinterpret_cast<const uint8_t*>(xin)[pix * 3 + (2 - ch)] - mean_rgb[ch];
-        } else {
-          v = reinterpret_cast<const float*>(xin)[pix * 3 + ch];
+  for (int yp = yp_first; yp < yp_first + kEnc1RowsPerWgF32 && yp < hp; ++yp) {
+    if (yp != yp_first) __syncthreads();  // the previous row's fragment reads are done
+    // ---- stage halo: rows 2yp-1..2yp+2, halo column c <-> input column c-1, 3 channels, preprocessed ------
+    if (U8 && (w & 3) == 0) {
+      const int gpr = w >> 2;  // groups of 4 pixels = 12 bytes = 3 aligned dwords
+      for (int e = tid; e < 4 * gpr; e += 256) {
+        const int hr = e / gpr, g = e % gpr;
+        const int iy = 2 * yp - 1 + hr;
+        unsigned d0 = 0, d1 = 0, d2 = 0;
+        const bool ok = (unsigned)iy < (unsigned)h;
+        if (ok) {
+          const unsigned int* p = reinterpret_cast<const unsigned int*>(reinterpret_cast<const uint8_t*>(xin) +
+                                                                        (((size_t)img * h + iy) * w + 4 * g) * 3);
+          d0 = p[0]; d1 = p[1]; d2 = p[2];
+        }
+        const unsigned by[12] = {d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, d0 >> 24, d1 & 255, (d1 >> 8) & 255,
+                                 (d1 >> 16) & 255, d1 >> 24, d2 & 255, (d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24};
+        float* dst = halo + hr * hs + (4 * g + 1) * 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // output channel ch (RGB order) = input channel 2-ch (BGR) minus that channel's mean
+          dst[3 * k + 0] = ok ? (float)by[3 * k + 2] - mean_rgb[0] : 0.f;
+          dst[3 * k + 1] = ok ? (float)by[3 * k + 1] - mean_rgb[1] : 0.f;
+          dst[3 * k + 2] = ok ? (float)by[3 * k + 0] - mean_rgb[2] : 0.f;
         }
       }
-      halo[hr * HALO_STRIDE + hc * 3 + ch] = v;
+      const int nz = hs - 3 * w;  // zero borders: column 0 and the floats past column w
+      for (int e = tid; e < 4 * nz; e += 256) {
+        const int hr = e / nz, z = e % nz;
+        halo[hr * hs + (z < 3 ? z : 3 * w + z)] = 0.f;
+      }
+    } else {
+      for (int e = tid; e < 4 * hs; e += 256) {
+        const int hr = e / hs, rest = e % hs;
+        const int hc = rest / 3, ch = rest % 3;
+        const int iy = 2 * yp - 1 + hr, ix = hc - 1;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) {
+          const size_t pix = ((size_t)img * h + iy) * w + ix;
+          if (U8) v = (float)reinterpret_cast<const uint8_t*>(xin)[pix * 3 + (2 - ch)] - mean_rgb[ch];
+          else v = reinterpret_cast<const float*>(xin)[pix * 3 + ch];
+        }
+        halo[e] = v;
+      }
     }
     __syncthreads();
 
-    f32x16 acc[2];
+    for (int xp0 = 0; xp0 < wp; xp0 += 32) {
+      const int pbase = dy * hs + (2 * (xp0 + q) + dx) * 3;
+      f32x16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float af[4];
+      for (int t = 0; t < 4; ++t) {
+        float af[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k0 = koff_of(8 * t + e), k1 = koff_of(8 * t + 4 + e);  // compile-time after unroll
-        const int off = lh ? k1 : k0;
-        af[e] = (off >= 0) ? halo[pbase + off] : 0.f;
-      }
+        for (int e = 0; e < 4; ++e) {
+          const int k0 = 8 * t + e, k1 = 8 * t + 4 + e;  // compile-time after unroll
+          const int off0 = (k0 < 27) ? (k0 / 9) * hs + (k0 % 9) : 0, off1 = (k1 < 27) ? (k1 / 9) * hs + (k1 % 9) : 0;
+          const bool v0 = k0 < 27, v1 = k1 < 27;
+          const float x = halo[pbase + (lh ? off1 : off0)];
+          af[e] = (lh ? v1 : v0) ? x : 0.f;
+        }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[j][t].x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[j][t].y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[j][t].z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[j][t].w, acc[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[j][t].x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[j][t].y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[j][t].z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[j][t].w, acc[j], 0, 0, 0);
+        }
       }
-    }
 
-    // epilogue: scale/shift (BN or bias), ReLU, then either the 2x2 max over registers 4g..4g+3 (pooled pixel
-    // xp0 + 8*wave + 2g + lh) or, for an un-pooled first layer (VGG block1_conv1), every conv output itself
+      // epilogue: scale/shift (BN or bias), ReLU, then either the 2x2 max over registers 4g..4g+3 (pooled pixel
+      // xp0 + 8*wave + 2g + lh) or, for an un-pooled first layer (VGG block1_conv1), every conv output itself
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int xp = xp0 + 8 * wave + 2 * g + lh;
-        if (POOL) {
-          float v = 0.f;  // ReLU floor
+        for (int g = 0; g < 4; ++g) {
+          const int xp = xp0 + 8 * wave + 2 * g + lh;
+          if (POOL) {
+            float v = 0.f;  // ReLU floor
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v = fmaxf(v, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
-          if (xp < wp) {
-            const size_t o = (((size_t)img * hp + yp) * wp + xp) * 64 + 32 * j + lr;
-            if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
-            else reinterpret_cast<float*>(f1)[o] = v;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {  // row 4g+e of the quad block: (dy, dx) = (e>>1, e&1)
-            const float v = fmaxf(0.f, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
-            const int y = 2 * yp + (e >> 1), x = 2 * xp + (e & 1);
+            for (int e = 0; e < 4; ++e) v = fmaxf(v, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
             if (xp < wp) {
-              const size_t o = (((size_t)img * h + y) * w + x) * 64 + 32 * j + lr;
+              const size_t o = (((size_t)img * hp + yp) * wp + xp) * 64 + 32 * j + lr;
               if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
               else reinterpret_cast<float*>(f1)[o] = v;
             }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // row 4g+e of the quad block: (dy, dx) = (e>>1, e&1)
+              const float v = fmaxf(0.f, fmaf(acc[j][4 * g + e], sc[j], sh[j]));
+              const int y = 2 * yp + (e >> 1), x = 2 * xp + (e & 1);
+              if (xp < wp) {
+                const size_t o = (((size_t)img * h + y) * w + x) * 64 + 32 * j + lr;
+                if (OBF) reinterpret_cast<unsigned short*>(f1)[o] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                else reinterpret_cast<float*>(f1)[o] = v;
+              }
+            }
           }
         }
-      }
+    }
   }
 }
-
 
 // ---- bf16 variant (BASELINE configs[2]) ----------------------------------------------------------------
 // Same layer on v_mfma_f32_32x32x16_bf16: the fp32 kernel above spends 0.9 ms of matrix time per 512 faces on
@@ -308,8 +339,10 @@ template <bool U8>
 static void launch_u(hipStream_t s, int blocks, const void* x, const float* w1p, const float* scale, const float* shift,
                      void* f1, int n, int h, int w, int out_bf16, int pool) {
   (void)out_bf16;  // bf16 output: enc1_bf16_kernel
-  if (pool) enc1_kernel<U8, false, true><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
-  else enc1_kernel<U8, false, false><<<blocks, 256, 0, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  const size_t lds = sizeof(float) * 4 * enc1_halo_stride(w);
+  blocks = n * (((h >> 1) + kEnc1RowsPerWgF32 - 1) / kEnc1RowsPerWgF32);
+  if (pool) enc1_kernel<U8, false, true><<<blocks, 256, lds, s>>>(x, w1p, scale, shift, f1, n, h, w);
+  else enc1_kernel<U8, false, false><<<blocks, 256, lds, s>>>(x, w1p, scale, shift, f1, n, h, w);
 }
 
 int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* w1p,
@@ -332,6 +365,10 @@ int launch_enc1(hipStream_t s, const void* x, int in_format, int n, int h, int w
     else launch_bf16_u<false>(s, blocks, x, w1p, scale, shift, f1, n, h, w, pool);
     FLM_LAUNCH_CHECK("enc1_bf16_kernel");
     return FLM_OK;
+  }
+  if (sizeof(float) * 4 * enc1_halo_stride(w) > 64 * 1024) {
+    set_error("enc1: input width %d exceeds the halo buffer", w);
+    return FLM_ERR_SHAPE;
   }
   if (in_format == FLM_IN_U8_BGR) {
     launch_u<true>(s, blocks, x, w1p, scale, shift, f1, n, h, w, out_bf16, pool);
