@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void cand_tau_kernel(const unsigned* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int face = blockIdx.x;
   const unsigned* src = wave_max + (size_t)face * slots * ld;
-  for (int c = wave; c < l; c += 4) {
+  for (int c = blockIdx.y * 4 + wave; c < l; c += 4 * gridDim.y) {  // one class per wave and round
     unsigned long long list = 0ull, t = 0ull;
     for (int s0 = 0; s0 < slots; s0 += 64) {
       const int sl = s0 + lane;
@@ -370,7 +370,7 @@ int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, i
     set_error("cand_tau: unsupported n_points=%d slots=%d", n_points, slots);
     return FLM_ERR_UNSUPPORTED;
   }
-  cand_tau_kernel<<<n, 256, 0, s>>>(wave_max, slots, ld, l, n_points, tau);
+  cand_tau_kernel<<<dim3(n, 6), 256, 0, s>>>(wave_max, slots, ld, l, n_points, tau);
   FLM_LAUNCH_CHECK("cand_tau_kernel");
   return FLM_OK;
 }
