@@ -171,6 +171,7 @@ struct ConvTDesc {
 };
 int launch_convt(hipStream_t s, const ConvTDesc& d);
 int convt_candidates_supported(const ConvTGeom& g);
+int convt_share_layout(const ConvTGeom& g, int s);
 int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub);
 int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau);
 

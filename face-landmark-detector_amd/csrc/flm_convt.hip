@@ -55,6 +55,7 @@ struct ConvTArgs {
   int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
   int ppf;  // > 0: positions per face padded to a multiple of the workgroup's tile (a workgroup never spans two faces)
   int ls;   // log2(s): the strides of the reference's decoders are 2, 8 and 32
+  int share;  // packed weights use the shared tile-4 layout (convt_share_layout): fp32 68-class kernels, s % 4 == 0
   int nb;   // phases b0 computed per phase row (s, or 1 for the sub-sampled launch)
   int sub;  // > 0: sampling launch: a workgroup computes `sub` phases chosen from its tile index (not a phase row);
             // epilogue 1 writes them compactly (pixel index (r, i0, j0) on a sub x (hi+1) x (wi+1) grid), epilogue 4
@@ -136,7 +137,22 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   // Phase (a0, b0) of iteration IT of this workgroup: phase row blockIdx.y, b0 = IT; in the sampling launch the
   // IT-th entry of the tile's list -- an odd stride walks all s*s phases before repeating.
   const int tile_pf = a.sub ? (int)(blockIdx.x % (a.ppf / (64 * NT))) : 0;
-#define FLM_PHASE(IT) (a.sub ? (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)) : ((int)blockIdx.y * s + (IT)))
+  // Shared tile-4 layout (a.share): the four extra classes 64..67 of FOUR consecutive phases b0 = 4gb .. 4gb+3 are
+  // rows 4q + j of the leader phase's tile 4 (X is the same for every phase, only the filter differs), so the short
+  // phases 4gb+1..3 stream and multiply 4 tiles instead of 5: 15 % fewer MFMAs and LDS weight reads.  In the sampling
+  // launch every fourth phase of a tile's list is a leader (all 68 classes), the rest any phase (classes 0..63 only).
+#define FLM_PHASE(IT)                                                                                    \
+  (a.sub ? ((a.share && !((IT) & 3))                                                                     \
+                ? ((((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s / 4 - 1)) / (s / 4) * s +               \
+                   4 * ((((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s / 4 - 1)) % (s / 4)))              \
+                : (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)))                                   \
+         : ((int)blockIdx.y * s + (IT)))
+  // float4 offset of a phase's weights and its tile count in the stream
+#define FLM_PHASE_MT(PH) ((a.share && ((PH) & 3)) ? 4 : MT)
+#define FLM_PHASE_OFF(PH)                                                                                \
+  (a.share ? ((size_t)(((PH) >> a.ls) * (s >> 2) + (((PH) & (s - 1)) >> 2)) * 17 +                       \
+              (((PH) & 3) ? 5 + 4 * (((PH) & 3) - 1) : 0)) * (size_t)(G * 64)                            \
+           : (size_t)(PH) * phase_f4)
 
   // ---- this lane's NT input positions (NT pixel tiles of 16 per wave: the phase's weights, streamed once
   //      per workgroup, then serve 64*NT positions) --------------------------------------------------
@@ -232,7 +248,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     const int sq_ = (SEQ);                                                              \
     const int b0_ = sq_ / NCH, ch_ = sq_ % NCH;                                         \
     /* (the last chunk of a phase is shorter: its tail reads the next phase's first groups, never used) */ \
-    const int soff_ = (int)(((size_t)FLM_PHASE(b0_) * phase_f4 + (size_t)ch_ * CHUNK_F4) * 16);  \
+    const int ph0_ = FLM_PHASE(b0_);                                                    \
+    const int soff_ = (int)((FLM_PHASE_OFF(ph0_) + (size_t)ch_ * GCH * FLM_PHASE_MT(ph0_) * 64) * 16); \
     FLM_FOR_ST(FLM_LD1)                                                                 \
   }
 #define FLM_STASH(BUF)                                                                  \
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     if (SAMPLE) {                                                                                 \
       /* class maxima over the wave's 16 pixels (lanes r of one q), then one LDS max per class */  \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
-       if (FLM_CVALID(m, e)) {                                                                    \
+       if (FLM_CVALID(m, e) && (m < MT - 1 || !C68 || !a.share || !(ph3_ & 3))) {                 \
         float v = ovalid ? pv[nt][m][e] : 0.f;                                                    \
         v = fmaxf(v, __shfl_xor(v, 1));                                                           \
         v = fmaxf(v, __shfl_xor(v, 2));                                                           \
@@ -397,11 +414,17 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 
   int seq = 0;
   // One phase: MFMAs into set ACC while the three parts finish the previous phase held in set PV.
-#define FLM_PHASE_BODY(ACC, PV, B0)                                                                 \
+#define FLM_PHASE_BODY(ACC, PV, B0, MTP, FILL, PJ, PPAR)                                            \
   {                                                                                                 \
     const int b0 = (B0);                                                                            \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int m = 0; m < MT; ++m) \
       ACC[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                     \
+    if (FILL) { /* the previous phase was a short one: its class 64+q value waits in the group's tile-4 sums */ \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
+        const f32x4 xs_ = (PPAR) ? x4g[1][nt] : x4g[0][nt];                                         \
+        PV[nt][MT - 1][0] = xs_[PJ];                                                                \
+      }                                                                                             \
+    }                                                                                               \
     _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                            \
       const bool more = seq + 1 < total;                                                            \
       if (more) FLM_ISSUE(seq + 1)                                                                  \
@@ -415,22 +438,22 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         const int g = ch * GCH + gl; /* compile-time */                                             \
         if (g < G) {                                                                                \
           float4 af[MT];                                                                            \
-          _Pragma("unroll") for (int m = 0; m < MT; ++m) af[m] = wl[(gl * MT + m) * 64 + lane];     \
+          _Pragma("unroll") for (int m = 0; m < (MTP); ++m) af[m] = wl[(gl * (MTP) + m) * 64 + lane]; \
           if constexpr (BF) {                                                                       \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
               const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);                              \
-              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+              _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
                 ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, ACC[nt][m], 0, 0, 0); \
             }                                                                                       \
           } else {                                                                                  \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
-              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+              _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
                 ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, ACC[nt][m], 0, 0, 0); \
-              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+              _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
                 ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, ACC[nt][m], 0, 0, 0); \
-              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+              _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
                 ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, ACC[nt][m], 0, 0, 0); \
-              _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+              _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
                 ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, ACC[nt][m], 0, 0, 0); \
             }                                                                                       \
           }                                                                                         \
@@ -441,9 +464,49 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       ++seq;                                                                                        \
     }                                                                                               \
   }
+  constexpr bool SHARE_OK = C68 && !BF;  // kernels that may meet the shared tile-4 layout
+  f32x4 x4g[2][NT];                      // tile-4 sums of the current and the previous group of four phases
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) x4g[0][nt] = x4g[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (SHARE_OK && a.share && !a.sub) {
+    // groups of four phases: leader (5 tiles, keeps the group's tile-4 sums), then three short phases
+    for (int g4 = 0; g4 < (a.nb >> 2); ++g4) {
+      const int par = g4 & 1;
+      FLM_PHASE_BODY(accA, accB, 4 * g4, MT, (g4 > 0), 3, (par ^ 1))
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (par) x4g[1][nt] = accA[nt][MT - 1];
+        else x4g[0][nt] = accA[nt][MT - 1];
+      }
+      FLM_PHASE_BODY(accB, accA, 4 * g4 + 1, MT - 1, false, 0, par)
+      FLM_PHASE_BODY(accA, accB, 4 * g4 + 2, MT - 1, true, 1, par)
+      FLM_PHASE_BODY(accB, accA, 4 * g4 + 3, MT - 1, true, 2, par)
+    }
+    {  // drain: phase nb-1 is the third short phase of the last group (set B)
+      const int par = ((a.nb >> 2) - 1) & 1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 xs_ = par ? x4g[1][nt] : x4g[0][nt];
+        accB[nt][MT - 1][0] = xs_[3];
+      }
+      FLM_EPI_PART1(accB)
+      FLM_EPI_PART2(accB, a.nb - 1)
+      FLM_EPI_PART3(accB, a.nb - 1)
+    }
+  } else {
   for (int bb = 0; bb < a.nb; bb += 2) {
-    FLM_PHASE_BODY(accA, accB, bb)
-    if (bb + 1 < a.nb) FLM_PHASE_BODY(accB, accA, bb + 1)
+    if (SHARE_OK && SAMPLE && a.share && (FLM_PHASE(bb) & 3)) {
+      FLM_PHASE_BODY(accA, accB, bb, MT - 1, false, 0, 0)
+    } else {
+      FLM_PHASE_BODY(accA, accB, bb, MT, false, 0, 0)
+    }
+    if (bb + 1 < a.nb) {
+      if (SHARE_OK && SAMPLE && a.share && (FLM_PHASE(bb + 1) & 3)) {
+        FLM_PHASE_BODY(accB, accA, bb + 1, MT - 1, false, 0, 0)
+      } else {
+        FLM_PHASE_BODY(accB, accA, bb + 1, MT, false, 0, 0)
+      }
+    }
   }
   // drain: the last phase's epilogue (even phase indices accumulate in set A)
   if (a.nb & 1) {
@@ -454,6 +517,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     FLM_EPI_PART1(accB)
     FLM_EPI_PART2(accB, a.nb - 1)
     FLM_EPI_PART3(accB, a.nb - 1)
+  }
   }
 #undef FLM_PHASE_BODY
   if (SAMPLE) {
@@ -486,6 +550,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 }
 
 #undef FLM_PHASE
+#undef FLM_PHASE_MT
+#undef FLM_PHASE_OFF
 #undef FLM_CVALID
 #undef FLM_CLS
 #undef FLM_EPI_PART1
@@ -530,6 +596,9 @@ int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub) {
   return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt) * sub;
 }
 
+// fp32 68-class kernels with a stride that is a multiple of 4 (up3: 8, fcn_32: 32) use the shared tile-4 layout.
+int convt_share_layout(const ConvTGeom& g, int s) { return !g.bf16 && g.C == 68 && g.G == 17 && (s % 4) == 0; }
+
 int convt_candidates_supported(const ConvTGeom& g) {
   return g.C == 68 && ((g.bf16 && g.G == 9) || (!g.bf16 && g.G == 17));
 }
@@ -540,6 +609,7 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
   a.n = d.n; a.hi = d.hi; a.wi = d.wi; a.ho = d.ho; a.wo = d.wo; a.s = d.s; a.ldy = d.ldy;
   a.epilogue = d.epilogue; a.C = d.g.C; a.Cp = d.g.Cp;
   a.sub = d.sub; a.nb = d.sub ? d.sub : d.s;
+  a.share = convt_share_layout(d.g, d.s);
   a.ls = 0;
   while ((1 << a.ls) < d.s) ++a.ls;
   if ((1 << a.ls) != d.s) {
