@@ -139,20 +139,16 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   const int tile_pf = a.sub ? (int)(blockIdx.x % (a.ppf / (64 * NT))) : 0;
   // Shared tile-4 layout (a.share): the four extra classes 64..67 of FOUR consecutive phases b0 = 4gb .. 4gb+3 are
   // rows 4q + j of the leader phase's tile 4 (X is the same for every phase, only the filter differs), so the short
-  // phases 4gb+1..3 stream and multiply 4 tiles instead of 5: 15 % fewer MFMAs and LDS weight reads.  In the sampling
-  // launch every fourth phase of a tile's list is a leader (all 68 classes), the rest any phase (classes 0..63 only).
+  // phases 4gb+1..3 multiply and read 4 tiles instead of 5 (their fifth tile in the stream is unused): 15 % fewer MFMAs.
+  // In the sampling launch every fourth phase of a tile's list is a leader (all 68 classes), the rest any phase
+  // (classes 0..63 only).
 #define FLM_PHASE(IT)                                                                                    \
   (a.sub ? ((a.share && !((IT) & 3))                                                                     \
                 ? ((((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s / 4 - 1)) / (s / 4) * s +               \
                    4 * ((((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s / 4 - 1)) % (s / 4)))              \
                 : (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)))                                   \
          : ((int)blockIdx.y * s + (IT)))
-  // float4 offset of a phase's weights and its tile count in the stream
-#define FLM_PHASE_MT(PH) ((a.share && ((PH) & 3)) ? 4 : MT)
-#define FLM_PHASE_OFF(PH)                                                                                \
-  (a.share ? ((size_t)(((PH) >> a.ls) * (s >> 2) + (((PH) & (s - 1)) >> 2)) * 17 +                       \
-              (((PH) & 3) ? 5 + 4 * (((PH) & 3) - 1) : 0)) * (size_t)(G * 64)                            \
-           : (size_t)(PH) * phase_f4)
+
 
   // ---- this lane's NT input positions (NT pixel tiles of 16 per wave: the phase's weights, streamed once
   //      per workgroup, then serve 64*NT positions) --------------------------------------------------
@@ -248,8 +244,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     const int sq_ = (SEQ);                                                              \
     const int b0_ = sq_ / NCH, ch_ = sq_ % NCH;                                         \
     /* (the last chunk of a phase is shorter: its tail reads the next phase's first groups, never used) */ \
-    const int ph0_ = FLM_PHASE(b0_);                                                    \
-    const int soff_ = (int)((FLM_PHASE_OFF(ph0_) + (size_t)ch_ * GCH * FLM_PHASE_MT(ph0_) * 64) * 16); \
+    const int soff_ = (int)(((size_t)FLM_PHASE(b0_) * phase_f4 + (size_t)ch_ * CHUNK_F4) * 16);  \
     FLM_FOR_ST(FLM_LD1)                                                                 \
   }
 #define FLM_STASH(BUF)                                                                  \
@@ -438,7 +433,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         const int g = ch * GCH + gl; /* compile-time */                                             \
         if (g < G) {                                                                                \
           float4 af[MT];                                                                            \
-          _Pragma("unroll") for (int m = 0; m < (MTP); ++m) af[m] = wl[(gl * (MTP) + m) * 64 + lane]; \
+          _Pragma("unroll") for (int m = 0; m < (MTP); ++m) af[m] = wl[(gl * MT + m) * 64 + lane];  \
           if constexpr (BF) {                                                                       \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
               const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);                              \
@@ -494,19 +489,9 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       FLM_EPI_PART3(accB, a.nb - 1)
     }
   } else {
-  for (int bb = 0; bb < a.nb; bb += 2) {
-    if (SHARE_OK && SAMPLE && a.share && (FLM_PHASE(bb) & 3)) {
-      FLM_PHASE_BODY(accA, accB, bb, MT - 1, false, 0, 0)
-    } else {
-      FLM_PHASE_BODY(accA, accB, bb, MT, false, 0, 0)
-    }
-    if (bb + 1 < a.nb) {
-      if (SHARE_OK && SAMPLE && a.share && (FLM_PHASE(bb + 1) & 3)) {
-        FLM_PHASE_BODY(accB, accA, bb + 1, MT - 1, false, 0, 0)
-      } else {
-        FLM_PHASE_BODY(accB, accA, bb + 1, MT, false, 0, 0)
-      }
-    }
+  for (int bb = 0; bb < a.nb; bb += 2) {  // (a sampling launch multiplies all five tiles: a short phase's fifth is unused)
+    FLM_PHASE_BODY(accA, accB, bb, MT, false, 0, 0)
+    if (bb + 1 < a.nb) FLM_PHASE_BODY(accB, accA, bb + 1, MT, false, 0, 0)
   }
   // drain: the last phase's epilogue (even phase indices accumulate in set A)
   if (a.nb & 1) {
@@ -550,8 +535,6 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 }
 
 #undef FLM_PHASE
-#undef FLM_PHASE_MT
-#undef FLM_PHASE_OFF
 #undef FLM_CVALID
 #undef FLM_CLS
 #undef FLM_EPI_PART1
@@ -595,9 +578,6 @@ int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub) {
   const int nt = g.bf16 ? 2 : 1;
   return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt) * sub;
 }
-
-// fp32 68-class kernels with a stride that is a multiple of 4 (up3: 8, fcn_32: 32) use the shared tile-4 layout.
-int convt_share_layout(const ConvTGeom& g, int s) { return !g.bf16 && g.C == 68 && g.G == 17 && (s % 4) == 0; }
 
 int convt_candidates_supported(const ConvTGeom& g) {
   return g.C == 68 && ((g.bf16 && g.G == 9) || (!g.bf16 && g.G == 17));

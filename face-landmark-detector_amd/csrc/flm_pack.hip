@@ -256,7 +256,8 @@ __global__ void pack_enc1_kernel(const float* __restrict__ src /*[3][3][3][64]*/
 // 8 (bf16) elements per lane:  class o = 16*mt + r, k = 4*EPL*g + EPL*q + e, tap = k / Cp = 2*di+dj, c = k % Cp.
 // The 68-class kernels (flm_convt.hip, C68) spread classes 64..67 over the last tile's rows 0, 4, 8, 12: in the
 // MFMA result row 4q + e belongs to lane group q, so every lane then holds 17 classes (16 + one) instead of lane
-// group 0 holding 20 and the others 16 + 4 dead values.
+// group 0 holding 20 and the others 16 + 4 dead values.  With convt_share_layout(g, s) those four rows carry the
+// four phases of a group instead (see flm_convt.hip).
 template <typename T>
 __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__ dst, int s, ConvTGeom g) {
   constexpr int EPL = 16 / (int)sizeof(T);
@@ -274,56 +275,25 @@ __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__
     const int gg = (int)(rem / g.MT);
     const int r = lane & 15, q = lane >> 4;
     int o = 16 * mt + r;
-    if (g.C == 68 && (g.G == 9 || g.G == 17) && mt == 4) o = (r & 3) == 0 ? 64 + (r >> 2) : g.C;  // g.C: no class
+    int a0 = phase / s, b0 = phase % s;
+    if (g.C == 68 && (g.G == 9 || g.G == 17) && mt == 4) {
+      if (convt_share_layout(g, s)) {
+        // shared fifth tile: in a leader phase (b0 % 4 == 0) row 4q' + j holds class 64+q' of phase b0 + j;
+        // the fifth tile of the other phases is not multiplied
+        o = (b0 & 3) == 0 ? 64 + (r >> 2) : g.C;
+        b0 += r & 3;
+      } else {
+        o = (r & 3) == 0 ? 64 + (r >> 2) : g.C;  // g.C: no class
+      }
+    }
     const int k = 4 * EPL * gg + EPL * q + e;
     const int tap = k / g.Cp, c = k % g.Cp;
     float v = 0.f;
     if (o < g.C && c < g.C && tap < 4) {
-      const int a0 = phase / s, b0 = phase % s;
       const int a = a0 + s * (tap >> 1), b = b0 + s * (tap & 1);
       v = src[(((size_t)a * ks + b) * g.C + o) * g.C + c];
     }
     put(dst, i, v);
-  }
-}
-
-// Shared tile-4 layout of the fp32 68-class kernels (flm_convt.hip, convt_share_layout): per phase row a0 and group
-// gb of four phases  [leader b0 = 4gb: G x 5 tiles][b0+1: G x 4 tiles][b0+2][b0+3]; the leader's tile 4 holds, in row
-// 4q + j, class 64+q of phase b0 + j.
-__global__ void pack_convt_share_kernel(const float* __restrict__ src, float* __restrict__ dst, int s, ConvTGeom g) {
-  const size_t grp_f = (size_t)17 * g.G * 64 * 4;  // floats per group of four phases
-  const size_t total = grp_f * s * (s / 4);
-  const int ks = 2 * s;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int grp = (int)(i / grp_f);
-    size_t rem = i % grp_f;
-    const int a0 = grp / (s / 4), gb = grp % (s / 4);
-    const size_t lead_f = (size_t)5 * g.G * 64 * 4, short_f = (size_t)4 * g.G * 64 * 4;
-    int j = 0, mtp = 5;
-    if (rem >= lead_f) {
-      j = 1 + (int)((rem - lead_f) / short_f);
-      rem = (rem - lead_f) % short_f;
-      mtp = 4;
-    }
-    const int e = (int)(rem & 3);
-    rem >>= 2;
-    const int lane = (int)(rem & 63);
-    rem >>= 6;
-    const int mt = (int)(rem % mtp), gg = (int)(rem / mtp);
-    const int r = lane & 15, q = lane >> 4;
-    int o = 16 * mt + r, b0 = 4 * gb + j;
-    if (mt == 4) {  // leader only: row 4q' + j' <- class 64 + q' of phase 4gb + j'
-      o = 64 + (r >> 2);
-      b0 = 4 * gb + (r & 3);
-    }
-    const int k = 16 * gg + 4 * q + e;
-    const int tap = k / g.Cp, c = k % g.Cp;
-    float v = 0.f;
-    if (o < g.C && c < g.C && tap < 4) {
-      const int a = a0 + s * (tap >> 1), b = b0 + s * (tap & 1);
-      v = src[(((size_t)a * ks + b) * g.C + o) * g.C + c];
-    }
-    dst[i] = v;
   }
 }
 
@@ -419,8 +389,6 @@ int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pac
     }
     if (L.dtype == FLM_BF16)
       pack_convt_kernel<unsigned short><<<4096, 256, 0, s>>>(p.up3, (unsigned short*)(blob + L.up3), 32, L.g);
-    else if (convt_share_layout(L.g, 32))
-      pack_convt_share_kernel<<<4096, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 32, L.g);
     else
       pack_convt_kernel<float><<<4096, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 32, L.g);
     FLM_LAUNCH_CHECK("pack_convt_kernel");
@@ -437,8 +405,7 @@ int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pac
   } else {
     pack_convt_kernel<float><<<256, 256, 0, s>>>(p.up5, (float*)(blob + L.up5), 2, L.g);
     pack_convt_kernel<float><<<256, 256, 0, s>>>(p.up4, (float*)(blob + L.up4), 2, L.g);
-    if (convt_share_layout(L.g, 8)) pack_convt_share_kernel<<<2048, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 8, L.g);
-    else pack_convt_kernel<float><<<2048, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 8, L.g);
+    pack_convt_kernel<float><<<2048, 256, 0, s>>>(p.up3, (float*)(blob + L.up3), 8, L.g);
   }
   FLM_LAUNCH_CHECK("pack_convt_kernel");
   return FLM_OK;
