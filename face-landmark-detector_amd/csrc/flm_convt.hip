@@ -139,15 +139,11 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   const int tile_pf = a.sub ? (int)(blockIdx.x % (a.ppf / (64 * NT))) : 0;
   // Shared tile-4 layout (a.share): the four extra classes 64..67 of FOUR consecutive phases b0 = 4gb .. 4gb+3 are
   // rows 4q + j of the leader phase's tile 4 (X is the same for every phase, only the filter differs), so the short
-  // phases 4gb+1..3 multiply and read 4 tiles instead of 5 (their fifth tile in the stream is unused): 15 % fewer MFMAs.
-  // In the sampling launch every fourth phase of a tile's list is a leader (all 68 classes), the rest any phase
-  // (classes 0..63 only).
+  // phases 4gb+1..3 multiply and read 4 tiles instead of 5: 15 % fewer MFMAs.  Their fifth tile in the stream still
+  // holds their own classes 64..67 (rows 4q): the sampling launch multiplies all five tiles of whatever phase it draws,
+  // so its probabilities are the main launch's bit for bit.
 #define FLM_PHASE(IT)                                                                                    \
-  (a.sub ? ((a.share && !((IT) & 3))                                                                     \
-                ? ((((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s / 4 - 1)) / (s / 4) * s +               \
-                   4 * ((((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s / 4 - 1)) % (s / 4)))              \
-                : (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)))                                   \
-         : ((int)blockIdx.y * s + (IT)))
+  (a.sub ? (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)) : ((int)blockIdx.y * s + (IT)))
 
 
   // ---- this lane's NT input positions (NT pixel tiles of 16 per wave: the phase's weights, streamed once
@@ -271,6 +267,23 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #pragma unroll
     for (int m = 0; m < MT; ++m) accA[nt][m] = accB[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // Candidate keys of this wave: LDS region -> the face's global list (one atomic reserves the range).  Runs at the
+  // end of the kernel and whenever the region would overflow (many classes peaking in the wave's 128 / 256 pixels).
+#define FLM_CAND_FLUSH()                                                                          \
+  {                                                                                               \
+    const unsigned found_ = __builtin_amdgcn_readfirstlane(wcnt);                                 \
+    if (wg_img < a.n && found_) {                                                                 \
+      unsigned base_ = 0;                                                                         \
+      if (lane == 0) {                                                                            \
+        base_ = atomicAdd(&a.cand_cnt[wg_img], found_);                                           \
+        if (base_ + found_ > (unsigned)a.cand_cap) atomicOr(&a.cand_cnt[a.n], 1u);                \
+      }                                                                                           \
+      base_ = __builtin_amdgcn_readfirstlane(base_);                                              \
+      for (unsigned i_ = lane; i_ < found_; i_ += 64)                                             \
+        if (base_ + i_ < (unsigned)a.cand_cap) a.cand[(size_t)wg_img * a.cand_cap + base_ + i_] = cwave[i_]; \
+    }                                                                                             \
+    wcnt = 0;                                                                                     \
+  }
 #define FLM_EPI_PART1(pv)                                                                         \
   if (a.epilogue != 0) {                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     if (SAMPLE) {                                                                                 \
       /* class maxima over the wave's 16 pixels (lanes r of one q), then one LDS max per class */  \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
-       if (FLM_CVALID(m, e) && (m < MT - 1 || !C68 || !a.share || !(ph3_ & 3))) {                 \
+       if (FLM_CVALID(m, e)) {                                                                    \
         float v = ovalid ? pv[nt][m][e] : 0.f;                                                    \
         v = fmaxf(v, __shfl_xor(v, 1));                                                           \
         v = fmaxf(v, __shfl_xor(v, 2));                                                           \
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         if (mk[0] | mk[1] | mk[2] | mk[3]) { /* wave-uniform, taken for about one m in eight */   \
           _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
             if (mk[e]) {                                                                          \
+              if (wcnt + 64u > (unsigned)kCandWaveCap) FLM_CAND_FLUSH()                           \
               const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),            \
                                                               __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u)); \
               const unsigned slot = wcnt + rank;                                                  \
@@ -517,26 +531,13 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         dst[i] = c < a.C ? wmax[it * 16 * MT + ((C68 && c >= 64) ? 64 + 4 * (c - 64) : c)] : 0u;
       }
   }
-  if (CAND && a.epilogue == 3) {
-    // flush this wave's keys to its face's list: one global atomic per wave, coalesced 8-byte stores
-    const unsigned found = __builtin_amdgcn_readfirstlane(wcnt);
-    const unsigned cnt = found < (unsigned)kCandWaveCap ? found : (unsigned)kCandWaveCap;
-    if (wg_img < a.n && found) {
-      unsigned base = 0;
-      if (lane == 0) {
-        base = atomicAdd(&a.cand_cnt[wg_img], cnt);
-        if (found > (unsigned)kCandWaveCap || base + cnt > (unsigned)a.cand_cap) atomicOr(&a.cand_cnt[a.n], 1u);
-      }
-      base = __builtin_amdgcn_readfirstlane(base);
-      for (unsigned i = lane; i < cnt; i += 64)
-        if (base + i < (unsigned)a.cand_cap) a.cand[(size_t)wg_img * a.cand_cap + base + i] = cwave[i];
-    }
-  }
+  if (CAND && a.epilogue == 3) FLM_CAND_FLUSH()
 }
 
 #undef FLM_PHASE
 #undef FLM_CVALID
 #undef FLM_CLS
+#undef FLM_CAND_FLUSH
 #undef FLM_EPI_PART1
 #undef FLM_EPI_PART2
 #undef FLM_EPI_PART3

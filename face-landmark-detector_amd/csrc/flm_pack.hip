@@ -278,10 +278,15 @@ __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__
     int a0 = phase / s, b0 = phase % s;
     if (g.C == 68 && (g.G == 9 || g.G == 17) && mt == 4) {
       if (convt_share_layout(g, s)) {
-        // shared fifth tile: in a leader phase (b0 % 4 == 0) row 4q' + j holds class 64+q' of phase b0 + j;
-        // the fifth tile of the other phases is not multiplied
-        o = (b0 & 3) == 0 ? 64 + (r >> 2) : g.C;
-        b0 += r & 3;
+        // shared fifth tile: in a leader phase (b0 % 4 == 0) row 4q' + j holds class 64+q' of phase b0 + j.  The
+        // other phases keep their own four classes in rows 4q' (as without sharing): the main launch does not
+        // multiply that tile, the sampling launch (any phase, all five tiles, register 0) does
+        if ((b0 & 3) == 0) {
+          o = 64 + (r >> 2);
+          b0 += r & 3;
+        } else {
+          o = (r & 3) == 0 ? 64 + (r >> 2) : g.C;
+        }
       } else {
         o = (r & 3) == 0 ? 64 + (r >> 2) : g.C;  // g.C: no class
       }

@@ -115,3 +115,30 @@ def test_candidate_path_on_a_non_square_input(flm, weights68, dtype):
         got = _landmarks(model, xd, n_points, 0.0, candidates=True)
         assert np.array_equal(got, ref), (dtype, n_points)
     assert ref[..., 0].max() < 168 and ref[..., 1].max() < 104
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_candidate_path_does_not_need_its_fallback_on_ordinary_maps(flm, weights68, dtype):
+    """The gated materialising launch keeps results exact when a list overflows or a class ends short of n keys, but it
+    doubles the cost: on the bench's maps the flag must stay clear and the lists far from full (a threshold taken from
+    probabilities that differ from the main launch's would trip the "fewer than n keys" check)."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    n = 6
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(np.random.default_rng(46).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
+    for n_points in (4, 25):
+        model._ws.clear()
+        model.forward_device(xd, "landmarks", n_points=n_points)
+        torch.cuda.synchronize()
+        ws = model._workspace(n, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN, n_points)
+
+        def off(name):
+            return lib.flm_fcn8_workspace_offset(name, n, 256, 256, 68, model._dt, _lib.OUT_LANDMARKS,
+                                                 _lib.DECODE_TOPN, n_points)
+        cap = off(b"cand_cap")
+        cnt = ws[off(b"cand_cnt"):off(b"cand_cnt") + 4 * (n + 1)].view(torch.int32).cpu().numpy()
+        assert cnt[n] == 0, (dtype, n_points, "fallback flag raised")
+        assert 68 * n_points <= cnt[:n].min() and cnt[:n].max() < cap // 2, (dtype, n_points, cnt[:n], cap)
