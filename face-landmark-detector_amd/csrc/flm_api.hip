@@ -412,9 +412,9 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     for (int i = 0; i < kMaxEnc; ++i) snprintf(enc_names[i], sizeof(enc_names[i]), "enc%d", i + 1);
     names_done = true;
   }
-  const bool fp32_only = A.enc[0].kind == ENC_MB_CONV1 || A.enc[0].kind == ENC_RN_CONV1;
-  if (fp32_only && bf) {
-    set_error("flm_fcn_forward: the MobileNet and ResNet50 encoders are built in fp32 only");
+  // bf16 implicit GEMMs need input channels in multiples of 64: MobileNet's first pointwise conv has 32
+  if (A.enc[0].kind == ENC_MB_CONV1 && bf) {
+    set_error("flm_fcn_forward: the MobileNet encoder is built in fp32 only");
     return FLM_ERR_UNSUPPORTED;
   }
   int hs[kMaxEnc], wsz[kMaxEnc];
@@ -441,17 +441,16 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
         rc = launch_enc1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, yout, bf, e.pool);
         break;
       case ENC_MB_CONV1:
-        rc = launch_mb_conv1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, reinterpret_cast<float*>(yout));
+        rc = launch_mb_conv1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, yout, bf);
         break;
       case ENC_RN_CONV1:
-        rc = launch_rn_conv1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, reinterpret_cast<float*>(yout));
+        rc = launch_rn_conv1(s, xin, in_format, n, hi, wi, w0, sc0, sh0, yout, bf);
         break;
       case ENC_MAXPOOL3:
-        rc = launch_maxpool3(s, reinterpret_cast<const float*>(xin), n, hi, wi, e.cin, reinterpret_cast<float*>(yout));
+        rc = launch_maxpool3(s, xin, n, hi, wi, e.cin, yout, bf);
         break;
       case ENC_MB_DW:
-        rc = launch_mb_depthwise(s, reinterpret_cast<const float*>(xin), n, hi, wi, e.cin, e.stride, w0, sc0, sh0,
-                                 reinterpret_cast<float*>(yout));
+        rc = launch_mb_depthwise(s, xin, n, hi, wi, e.cin, e.stride, w0, sc0, sh0, yout, bf);
         break;
       case ENC_CONV3:
         rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu*/ 1, e.pool, 0, dtype);

@@ -179,13 +179,14 @@ __host__ __device__ inline int convt_share_layout(const ConvTGeom& g, int s) {
 int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub);
 int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau);
 
+// (activations fp32, or bf16 when `bf16`)
 int launch_mb_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
-                    const float* scale, const float* shift, float* y);
-int launch_mb_depthwise(hipStream_t s, const float* x, int n, int h, int w, int c, int stride, const float* wgt,
-                        const float* scale, const float* shift, float* y);
+                    const float* scale, const float* shift, void* y, int bf16);
+int launch_mb_depthwise(hipStream_t s, const void* x, int n, int h, int w, int c, int stride, const float* wgt,
+                        const float* scale, const float* shift, void* y, int bf16);
 int launch_rn_conv1(hipStream_t s, const void* x, int in_format, int n, int h, int w, const float* wgt,
-                    const float* scale, const float* shift, float* y);
-int launch_maxpool3(hipStream_t s, const float* x, int n, int h, int w, int c, float* y);
+                    const float* scale, const float* shift, void* y, int bf16);
+int launch_maxpool3(hipStream_t s, const void* x, int n, int h, int w, int c, void* y, int bf16);
 
 size_t decode_ws_bytes(int n, int h, int w, int l, int mode, int n_points);
 int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, int ld, int mode, int n_points,

@@ -335,15 +335,10 @@ class Fcn8Resnet50Model(Fcn8Model):
     """fcn_8 on the ResNet50 encoder (networks/fcn.py:167-171, networks/resnet50.py:122-182), built without the
     ImageNet download: 7x7/s2 stem + 3x3/s2 'valid' max-pool (a 256x256 input gives 63x63 at stage 2) and 16
     bottleneck blocks with fused residual adds; f3/f4/f5 have 512/1024/2048 channels.  Tensors carry the Keras
-    layer names (`res3a_branch2b/kernel|bias`, `bn3a_branch2b/gamma|...`).  fp32 only."""
+    layer names (`res3a_branch2b/kernel|bias`, `bn3a_branch2b/gamma|...`).  fp32 or bf16."""
     model_name = "fcn_8_resnet50"
     _arch = _lib.ARCH_FCN8_RESNET50
     _enc_layers = _RESNET_LAYERS
-
-    def __init__(self, n_classes, input_height=416, input_width=608, channels=3, dtype="f32"):
-        if dtype != "f32":
-            raise NotImplementedError("the ResNet50 encoder is built in fp32 only")
-        super().__init__(n_classes, input_height, input_width, channels, dtype)
 
     def intermediate(self, name, n, out="probs", n_points=0):
         raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")

@@ -318,3 +318,25 @@ def test_resnet50_variants(flm):
         got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
         assert got.shape == exp.shape
         assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
+
+
+def test_resnet50_bf16_close_to_fp32(flm):
+    """bf16 operands / activations through the 53-conv ResNet50 encoder (strided 1x1 convs and residual adds on the
+    bf16 implicit GEMM, bf16 stem and max-pool): the probabilities stay a distribution and close to the exact-fp32
+    path; not gated at the fp32 bar (8 significant bits per operand, 50 layers deep)."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_resnet50_weights
+    rng = np.random.default_rng(36)
+    for name, fcn32, (n, h, w) in (("fcn_8_resnet50", False, (2, 256, 256)), ("fcn_32_resnet50", True, (1, 64, 96))):
+        params = synth_resnet50_weights(68, seed=6, fcn32=fcn32)
+        xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        out = {}
+        for dtype in ("f32", "bf16"):
+            model = LANDMARKS_MODELS[name](68, input_height=h, input_width=w, dtype=dtype)
+            model.load_weights(params)
+            out[dtype] = model.forward_device(xd, "probs").cpu().numpy()
+        assert np.isfinite(out["bf16"]).all()
+        assert np.abs(out["bf16"].sum(-1) - 1).max() < 1e-5
+        d = np.abs(out["bf16"] - out["f32"])
+        print(name, "bf16 vs fp32 probs: max %.3g mean %.3g" % (d.max(), d.mean()))
+        assert d.mean() < 2e-3 and d.max() < 0.2, (name, d.max(), d.mean())
