@@ -509,11 +509,13 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   a.gm = a.gn = 1;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
-  // The slice count depends on the layer only, not on the batch: every batch that is split at all (<= 64 tiles:
-  // up to 4 faces for fc6 / fc7) sums in the same order, so a face's result does not depend on its neighbours.
-  if (d.splitk_ws && !d.pool && !d.res && stride == 1 && tiles <= 64 &&
+  // The slice count is a step function of the tile count, the same for fc6 and fc7 (<= 64 tiles, i.e. up to 4
+  // faces: 8 slices; up to 8 faces: 4; up to 16: 2): batches inside one bracket sum in the same order, so a face's
+  // result does not depend on its neighbours there.
+  const int tile_cap = d.cout >= 1024 ? 256 : 64;  // the wide fc layers keep splitting until they fill the chip
+  if (d.splitk_ws && !d.pool && !d.res && stride == 1 && tiles <= tile_cap &&
       (d.kh * d.kw == 1 ? a.cpt >= 32 : a.cpt >= 4) && d.relu != 2) {
-    int ks = 8;
+    int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
     const int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
     if (ks > a.cpt / per) ks = a.cpt / per;
     if (ks > 1 && (size_t)ks * a.M * d.ldc * sizeof(float) <= d.splitk_ws_bytes) {
