@@ -453,7 +453,8 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
         rc = launch_mb_depthwise(s, xin, n, hi, wi, e.cin, e.stride, w0, sc0, sh0, yout, bf);
         break;
       case ENC_CONV3:
-        rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu*/ 1, e.pool, 0, dtype);
+        rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu*/ 1, e.pool, 0, dtype, 0,
+                        reinterpret_cast<float*>(ws + W.splitk), W.splitk_bytes);
         break;
       case ENC_MB_PW:
         rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu6*/ 2, 0, 0, dtype);

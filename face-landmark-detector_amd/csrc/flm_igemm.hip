@@ -359,7 +359,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int mbase = m0 + 64 * wr + 32 * i;
-      if (MMAP == 1) {
+      if (MMAP == 1 && a.ksplit > 1) {  // raw partial sums in quad order; BN / ReLU / pool happen in the reduce
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (cok && m < a.M) a.part[((size_t)blockIdx.y * a.M + m) * a.ldc + col] = acc[i][j][r];
+        }
+      } else if (MMAP == 1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v = -3.402823466e38f;
@@ -444,6 +450,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
   }
 }
 
+// Pooled layers: y[q][c] = max over the quad's four rows of act(scale[c] * sum_s part[s][4q+e][c] + shift[c]).
+__global__ void splitk_reduce_pool_kernel(const float* __restrict__ part, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, void* __restrict__ y, int M, int ldc, int cout,
+                                          int ksplit, int relu, float relu_max, int out_bf16) {
+  const size_t total = (size_t)(M >> 2) * ldc, plane = (size_t)M * ldc;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldc);
+    if (c >= cout) continue;
+    const size_t q = i / ldc;
+    float best = -3.402823466e38f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = 0.f;
+      for (int s = 0; s < ksplit; ++s) v += part[(size_t)s * plane + (4 * q + e) * ldc + c];
+      v = fmaf(v, scale[c], shift[c]);
+      if (relu) v = fminf(fmaxf(v, 0.f), relu_max);
+      best = fmaxf(best, v);
+    }
+    if (out_bf16) reinterpret_cast<unsigned short*>(y)[i] = f2bf(best);
+    else reinterpret_cast<float*>(y)[i] = best;
+  }
+}
+
 int igemm_occupancy(size_t lds_bytes) {
   int nb = -1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&igemm_kernel<false, 0, true>), 256,
@@ -511,10 +540,11 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
   // The slice count is a step function of the tile count, the same for fc6 and fc7 (<= 64 tiles, i.e. up to 4
   // faces: 8 slices; up to 8 faces: 4; up to 16: 2): batches inside one bracket sum in the same order, so a face's
-  // result does not depend on its neighbours there.
+  // result does not depend on its neighbours there.  Pooled 3x3 layers join in when they have 8 chunks per tap (enc4,
+  // enc5: 16 and 4 workgroups for one face); their reduce applies BN / ReLU and the 2x2 max to the summed quads.
   const int tile_cap = d.cout >= 1024 ? 256 : 64;  // the wide fc layers keep splitting until they fill the chip
-  if (d.splitk_ws && !d.pool && !d.res && stride == 1 && tiles <= tile_cap &&
-      (d.kh * d.kw == 1 ? a.cpt >= 32 : a.cpt >= 4) && d.relu != 2) {
+  if (d.splitk_ws && !d.res && stride == 1 && tiles <= tile_cap && (!d.pool || (a.M & 3) == 0) &&
+      (d.kh * d.kw == 1 ? a.cpt >= 32 : (d.pool ? a.cpt >= 8 : a.cpt >= 4)) && (d.relu != 2 || d.pool)) {
     int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
     const int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
     if (ks > a.cpt / per) ks = a.cpt / per;
@@ -537,6 +567,12 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   if (rc || a.ksplit <= 1) return rc;
   const size_t total = (size_t)a.M * d.ldc;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  if (d.pool) {
+    splitk_reduce_pool_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, a.y, a.M, d.ldc, d.cout, a.ksplit, d.relu,
+                                                     a.relu_max, d.bf16 && !d.out_f32);
+    FLM_LAUNCH_CHECK("splitk_reduce_pool_kernel");
+    return FLM_OK;
+  }
   splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a.part, a.scale, a.shift, a.y, a.M, d.ldc, d.cout, a.ksplit, d.relu,
                                               d.bf16 && !d.out_f32);
   FLM_LAUNCH_CHECK("splitk_reduce_kernel");
