@@ -171,10 +171,10 @@ struct ConvTDesc {
 };
 int launch_convt(hipStream_t s, const ConvTDesc& d);
 int convt_candidates_supported(const ConvTGeom& g);
-// fp32 68-class kernels with a stride that is a multiple of 4 (up3: 8, fcn_32: 32) share the fifth class tile between
+// 68-class kernels with a stride that is a multiple of 4 (up3: 8, fcn_32: 32) share the fifth class tile between
 // four consecutive phases (flm_convt.hip, flm_pack.hip).
 __host__ __device__ inline int convt_share_layout(const ConvTGeom& g, int s) {
-  return !g.bf16 && g.C == 68 && g.G == 17 && (s % 4) == 0;
+  return g.C == 68 && (g.bf16 ? g.G == 9 : g.G == 17) && (s % 4) == 0;
 }
 int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub);
 int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau);

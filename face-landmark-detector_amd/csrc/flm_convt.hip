@@ -102,7 +102,7 @@ __device__ __forceinline__ float max_raw(float a, float b) {
 }
 
 // MODE: 0 = epilogues 0/1/2 (maps), 1 = epilogue 3 (top-n candidates), 2 = epilogue 4 (sampling launch: wave maxima)
-template <int MT, int G, bool BF, int NT, int MODE>
+template <int MT, int G, bool BF, int NT, int MODE, bool SHARE>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
   constexpr bool SAMPLE = MODE == 2;
@@ -123,11 +123,14 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   // candidate keys: one private LDS region per wave, filled through a wave-uniform counter (no atomics)
-  unsigned long long* cwave = reinterpret_cast<unsigned long long*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4) + wave * kCandWaveCap;
-  float* tau_s = reinterpret_cast<float*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 + sizeof(unsigned long long) * 4 * kCandWaveCap);  // [16*MT]
+  // (bf16 68-class kernels first keep the shared fifth tile's group sums here: [2 groups][NT][64 lanes] x 16 bytes per wave)
+  constexpr size_t X4_BYTES = (BF && MT == 5 && G == 9) ? sizeof(float4) * 4 * 2 * NT * 64 : 0;
+  float4* x4s = reinterpret_cast<float4*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4) + wave * 2 * NT * 64;
+  unsigned long long* cwave = reinterpret_cast<unsigned long long*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 + X4_BYTES) + wave * kCandWaveCap;
+  float* tau_s = reinterpret_cast<float*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 + X4_BYTES + sizeof(unsigned long long) * 4 * kCandWaveCap);  // [16*MT]
   unsigned wcnt = 0;
   // sampling launch (epilogue 4): per-wave class maxima as float bit patterns (p >= 0: unsigned order = float order)
-  unsigned* wmax = reinterpret_cast<unsigned*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 +
+  unsigned* wmax = reinterpret_cast<unsigned*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 + X4_BYTES +
                                                (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0)) +
                    wave * kMaxSamplePhases * 16 * MT;  // [phase of the tile's list][result row]
   if (SAMPLE)
@@ -430,8 +433,12 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       ACC[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                     \
     if (FILL) { /* the previous phase was a short one: its class 64+q value waits in the group's tile-4 sums */ \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
-        const f32x4 xs_ = (PPAR) ? x4g[1][nt] : x4g[0][nt];                                         \
-        PV[nt][MT - 1][0] = xs_[PJ];                                                                \
+        if constexpr (BF) {                                                                         \
+          PV[nt][MT - 1][0] = reinterpret_cast<const float*>(x4s + ((PPAR) * NT + nt) * 64 + lane)[PJ]; \
+        } else {                                                                                    \
+          const f32x4 xs_ = (PPAR) ? x4g[1][nt] : x4g[0][nt];                                       \
+          PV[nt][MT - 1][0] = xs_[PJ];                                                              \
+        }                                                                                           \
       }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                            \
@@ -473,19 +480,23 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       ++seq;                                                                                        \
     }                                                                                               \
   }
-  constexpr bool SHARE_OK = C68 && !BF;  // kernels that may meet the shared tile-4 layout
-  f32x4 x4g[2][NT];                      // tile-4 sums of the current and the previous group of four phases
+  constexpr bool SHARE_OK = C68;         // kernels that may meet the shared tile-4 layout
+  f32x4 x4g[2][BF ? 1 : NT];             // fp32: tile-4 sums of the current and the previous group of four phases (bf16: LDS)
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) x4g[0][nt] = x4g[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (SHARE_OK && a.share && !a.sub) {
+  for (int nt = 0; nt < (BF ? 1 : NT); ++nt) x4g[0][nt] = x4g[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (SHARE_OK && SHARE && !SAMPLE) {
     // groups of four phases: leader (5 tiles, keeps the group's tile-4 sums), then three short phases
     for (int g4 = 0; g4 < (a.nb >> 2); ++g4) {
       const int par = g4 & 1;
       FLM_PHASE_BODY(accA, accB, 4 * g4, MT, (g4 > 0), 3, (par ^ 1))
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        if (par) x4g[1][nt] = accA[nt][MT - 1];
-        else x4g[0][nt] = accA[nt][MT - 1];
+        if constexpr (BF) {
+          x4s[(par * NT + nt) * 64 + lane] = make_float4(accA[nt][MT - 1][0], accA[nt][MT - 1][1], accA[nt][MT - 1][2], accA[nt][MT - 1][3]);
+        } else {
+          if (par) x4g[1][nt] = accA[nt][MT - 1];
+          else x4g[0][nt] = accA[nt][MT - 1];
+        }
       }
       FLM_PHASE_BODY(accB, accA, 4 * g4 + 1, MT - 1, false, 0, par)
       FLM_PHASE_BODY(accA, accB, 4 * g4 + 2, MT - 1, true, 1, par)
@@ -495,8 +506,12 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       const int par = ((a.nb >> 2) - 1) & 1;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 xs_ = par ? x4g[1][nt] : x4g[0][nt];
-        accB[nt][MT - 1][0] = xs_[3];
+        if constexpr (BF) {
+          accB[nt][MT - 1][0] = reinterpret_cast<const float*>(x4s + (par * NT + nt) * 64 + lane)[3];
+        } else {
+          const f32x4 xs_ = par ? x4g[1][nt] : x4g[0][nt];
+          accB[nt][MT - 1][0] = xs_[3];
+        }
       }
       FLM_EPI_PART1(accB)
       FLM_EPI_PART2(accB, a.nb - 1)
@@ -547,18 +562,19 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #undef FLM_LD1
 #undef FLM_ST1
 
-template <int MT, int G, bool BF, int NT = 1, int MODE = 0>
+template <int MT, int G, bool BF, int NT = 1, int MODE = 0, bool SHARE = false>
 static int launch_t(hipStream_t st, ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
-  constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64 + (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0) +
+  constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64 + ((BF && MT == 5 && G == 9) ? sizeof(float4) * 4 * 2 * NT * 64 : 0) +
+                         (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0) +
                          (MODE == 2 ? sizeof(unsigned) * 4 * kMaxSamplePhases * 16 * MT : 0);
   // two workgroups per CU (160 KiB of LDS) is what the 68-class kernels are scheduled for: a key buffer that pushed the
   // fp32 candidate kernel to 94 KiB cost 22 % of up3
   static_assert(!(MT == 5 && (G == 9 || G == 17)) || MODE == 2 || lds <= 80 * 1024, "convt: LDS budget of two workgroups per CU");
   static bool attr_done = false;
   if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT, MODE>),
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT, MODE, SHARE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
@@ -568,7 +584,7 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
     xblocks = a.n * (a.ppf / (64 * NT));
   }
   dim3 grid(xblocks, a.sub ? 1 : a.s);
-  convt_kernel<MT, G, BF, NT, MODE><<<grid, 256, lds, st>>>(a);
+  convt_kernel<MT, G, BF, NT, MODE, SHARE><<<grid, 256, lds, st>>>(a);
   FLM_LAUNCH_CHECK("convt_kernel");
   return FLM_OK;
 }
@@ -614,7 +630,11 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
       set_error("convt: candidate epilogue needs the 68-class kernels, its buffers and a map below 2^17 pixels");
       return FLM_ERR_UNSUPPORTED;
     }
-    return d.g.bf16 ? launch_t<5, 9, true, 2, 1>(st, a) : launch_t<5, 17, false, 1, 1>(st, a);
+    if (!a.share) {
+      set_error("convt: the candidate epilogue is built for strides that are multiples of 4");
+      return FLM_ERR_UNSUPPORTED;
+    }
+    return d.g.bf16 ? launch_t<5, 9, true, 2, 1, true>(st, a) : launch_t<5, 17, false, 1, 1, true>(st, a);
   }
   if (d.epilogue == 4) {
     if (!convt_candidates_supported(d.g) || d.sub < 1 || d.sub > kMaxSamplePhases || !d.y) {
@@ -626,7 +646,7 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
   if (d.g.bf16) {
     // two pixel tiles per wave: at 16x the matrix rate the phase weights (45 KiB per 64 positions) are the
     // stream to economise
-    if (d.g.C == 68 && d.g.G == 9) return launch_t<5, 9, true, 2>(st, a);
+    if (d.g.C == 68 && d.g.G == 9) return a.share ? launch_t<5, 9, true, 2, 0, true>(st, a) : launch_t<5, 9, true, 2, 0, false>(st, a);
     switch (d.g.MT) {
       case 1: return launch_t<1, 2, true>(st, a);
       case 2: return launch_t<2, 4, true>(st, a);
@@ -636,7 +656,7 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
       case 6: return launch_t<6, 12, true>(st, a);
     }
   } else {
-    if (d.g.C == 68 && d.g.G == 17) return launch_t<5, 17, false>(st, a);
+    if (d.g.C == 68 && d.g.G == 17) return a.share ? launch_t<5, 17, false, 1, 0, true>(st, a) : launch_t<5, 17, false, 1, 0, false>(st, a);
     switch (d.g.MT) {
       case 1: return launch_t<1, 4, false>(st, a);
       case 2: return launch_t<2, 8, false>(st, a);
