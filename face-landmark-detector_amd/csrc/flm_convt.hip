@@ -55,7 +55,8 @@ struct ConvTArgs {
   int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
   int ppf;  // > 0: positions per face padded to a multiple of the workgroup's tile (a workgroup never spans two faces)
   int ls;   // log2(s): the strides of the reference's decoders are 2, 8 and 32
-  int share;  // packed weights use the shared tile-4 layout (convt_share_layout): fp32 68-class kernels, s % 4 == 0
+  int share;  // packed weights use the shared tile-4 layout (convt_share_layout): 68-class kernels, s % 4 == 0;
+              // the main launches then run the SHARE = true instantiation (template parameter)
   int nb;   // phases b0 computed per phase row (s, or 1 for the sub-sampled launch)
   int sub;  // > 0: sampling launch: a workgroup computes `sub` phases chosen from its tile index (not a phase row);
             // epilogue 1 writes them compactly (pixel index (r, i0, j0) on a sub x (hi+1) x (wi+1) grid), epilogue 4
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   // Phase (a0, b0) of iteration IT of this workgroup: phase row blockIdx.y, b0 = IT; in the sampling launch the
   // IT-th entry of the tile's list -- an odd stride walks all s*s phases before repeating.
   const int tile_pf = a.sub ? (int)(blockIdx.x % (a.ppf / (64 * NT))) : 0;
-  // Shared tile-4 layout (a.share): the four extra classes 64..67 of FOUR consecutive phases b0 = 4gb .. 4gb+3 are
+  // Shared tile-4 layout (template SHARE, packed weights per convt_share_layout): the four extra classes 64..67 of FOUR consecutive phases b0 = 4gb .. 4gb+3 are
   // rows 4q + j of the leader phase's tile 4 (X is the same for every phase, only the filter differs), so the short
   // phases 4gb+1..3 multiply and read 4 tiles instead of 5: 15 % fewer MFMAs.  Their fifth tile in the stream still
   // holds their own classes 64..67 (rows 4q): the sampling launch multiplies all five tiles of whatever phase it draws,
