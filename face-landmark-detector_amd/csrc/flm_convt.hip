@@ -353,9 +353,11 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         mk[2] = FLM_CVALID(m, 2) ? __ballot(pv[nt][m][2] >= tq.z) : 0ull;                         \
         mk[3] = FLM_CVALID(m, 3) ? __ballot(pv[nt][m][3] >= tq.w) : 0ull;                         \
         if (mk[0] | mk[1] | mk[2] | mk[3]) { /* wave-uniform, taken for about one m in eight */   \
+          /* room for the up to 4 x 64 keys of this group (one copy of the flush per group: the kernel's code   */ \
+          /* already exceeds the instruction cache)                                                              */ \
+          if (wcnt + 256u > (unsigned)kCandWaveCap) FLM_CAND_FLUSH()                              \
           _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
             if (mk[e]) {                                                                          \
-              if (wcnt + 64u > (unsigned)kCandWaveCap) FLM_CAND_FLUSH()                           \
               const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),            \
                                                               __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u)); \
               const unsigned slot = wcnt + rank;                                                  \
