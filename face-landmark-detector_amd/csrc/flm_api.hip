@@ -412,11 +412,6 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     for (int i = 0; i < kMaxEnc; ++i) snprintf(enc_names[i], sizeof(enc_names[i]), "enc%d", i + 1);
     names_done = true;
   }
-  // bf16 implicit GEMMs need input channels in multiples of 64: MobileNet's first pointwise conv has 32
-  if (A.enc[0].kind == ENC_MB_CONV1 && bf) {
-    set_error("flm_fcn_forward: the MobileNet encoder is built in fp32 only");
-    return FLM_ERR_UNSUPPORTED;
-  }
   int hs[kMaxEnc], wsz[kMaxEnc];
   enc_dims(A, h, w, hs, wsz);
   {
@@ -457,7 +452,22 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
                         reinterpret_cast<float*>(ws + W.splitk), W.splitk_bytes);
         break;
       case ENC_MB_PW:
-        rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu6*/ 2, 0, 0, dtype);
+        if (L.enc[i].cin != e.cin) {
+          // pixel-pair form (flm_pack.hip): half as many "pixels", twice the channels.  A 1x1 conv sees a flat list
+          // of pixels, so pairs may run across row ends: any even dimension can be the one that is halved
+          int pn = n, ph = hi, pw = wi;
+          if (!(pw & 1)) pw >>= 1;
+          else if (!(ph & 1)) ph >>= 1;
+          else if (!(pn & 1)) pn >>= 1;
+          else {
+            set_error("flm_fcn_forward: the paired pointwise conv needs an even number of pixels per batch");
+            rc = FLM_ERR_SHAPE;
+            break;
+          }
+          rc = conv_layer(s, blob, L.enc[i], xin, yout, pn, ph, pw, /*relu6*/ 2, 0, 0, dtype);
+        } else {
+          rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, /*relu6*/ 2, 0, 0, dtype);
+        }
         break;
       case ENC_CONV:
         rc = conv_layer(s, blob, L.enc[i], xin, yout, n, hi, wi, e.relu, 0, 0, dtype, 0, nullptr, 0, e.stride,

@@ -178,7 +178,11 @@ Fcn8Pack fcn8_pack_layout(int C, int dtype, int arch) {
       c.shift = take(cur, sizeof(float) * e.cin);
       L.enc[i] = c;
     } else if (e.kind == ENC_MB_PW) {
-      L.enc[i] = conv_pack(cur, 1, 1, 0, e.cin, e.cout, (int)align_up(e.cout, 128), es);
+      // bf16 implicit GEMMs take input channels in multiples of 64: the 32-channel pointwise conv (MobileNet block 1)
+      // is run on PAIRS of neighbouring pixels -- [M][32] read as [M/2][64] against the block-diagonal filter
+      // [[W,0],[0,W]] gives [M/2][2*cout], which is [M][cout] in memory
+      const int pair = (dtype == FLM_BF16 && e.cin == 32) ? 2 : 1;
+      L.enc[i] = conv_pack(cur, 1, 1, 0, e.cin * pair, e.cout * pair, (int)align_up(e.cout * pair, 128), es);
     } else if (e.kind == ENC_CONV) {
       L.enc[i] = conv_pack(cur, e.k, e.k, e.k / 2, e.cin, e.cout, (int)align_up(e.cout, 128), es);
     } else if (e.kind == ENC_MAXPOOL3) {
@@ -302,6 +306,29 @@ __global__ void pack_convt_kernel(const float* __restrict__ src, T* __restrict__
   }
 }
 
+// Pixel-pair form of a 1x1 conv (see fcn8_pack_layout): dst[o'][c'] = src[c' % cin][o' % cout] when o' / cout == c' / cin.
+__global__ void pack_pw_pair_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int cin, int cout,
+                                    int coutpad) {
+  const int K = 2 * cin;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= coutpad * K) return;
+  const int o = i / K, c = i % K;
+  float v = 0.f;
+  if (o < 2 * cout && o / cout == c / cin) v = src[(size_t)(c % cin) * cout + (o % cout)];
+  dst[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+// the two halves share one set of per-channel scale / shift
+__global__ void dup_affine_kernel(float* __restrict__ scale, float* __restrict__ shift, int cout, int coutpad) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= cout && o < 2 * cout) {
+    scale[o] = scale[o - cout];
+    shift[o] = shift[o - cout];
+  } else if (o >= 2 * cout && o < coutpad) {
+    scale[o] = 0.f;
+    shift[o] = 0.f;
+  }
+}
+
 static int pack_conv(hipStream_t s, const flm_conv_params& p, const ConvPack& c, char* blob, int dtype) {
   if (!p.kernel) {
     set_error("flm_fcn_pack: conv layer lacks its kernel");
@@ -362,6 +389,21 @@ int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pac
       pack_affine_kernel<<<cdiv(e.cin, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),
                                                           (float*)(blob + L.enc[i].shift), e.cin, e.cin);
       FLM_LAUNCH_CHECK("pack_affine_kernel");
+      continue;
+    }
+    if (e.kind == ENC_MB_PW && L.enc[i].cin != e.cin) {  // pixel-pair form (bf16, 32 input channels)
+      if (!q.kernel) {
+        set_error("flm_fcn_pack: conv layer lacks its kernel");
+        return FLM_ERR_ARG;
+      }
+      const int total = L.enc[i].coutpad * 2 * e.cin;
+      pack_pw_pair_kernel<<<cdiv(total, 256), 256, 0, s>>>(q.kernel, (unsigned short*)(blob + L.enc[i].w), e.cin, e.cout,
+                                                           L.enc[i].coutpad);
+      pack_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>(q, (float*)(blob + L.enc[i].scale),
+                                                                     (float*)(blob + L.enc[i].shift), e.cout, e.cout);
+      dup_affine_kernel<<<cdiv(L.enc[i].coutpad, 256), 256, 0, s>>>((float*)(blob + L.enc[i].scale),
+                                                                    (float*)(blob + L.enc[i].shift), e.cout, L.enc[i].coutpad);
+      FLM_LAUNCH_CHECK("pack_pw_pair_kernel");
       continue;
     }
     int rc = pack_conv(s, q, L.enc[i], blob, L.dtype);

@@ -295,14 +295,12 @@ class Fcn8MobilenetModel(Fcn8Model):
     """fcn_8 on the MobileNet-v1 encoder (networks/fcn.py:181-185, networks/mobilenet.py:59-114; alpha 1),
     built without the ImageNet download.  Tensors carry the Keras layer names: `conv1/kernel`,
     `conv_dw_i/depthwise_kernel` (3,3,C,1), `conv_pw_i/kernel`, and `<layer>_bn/gamma|beta|moving_mean|
-    moving_variance`; no biases.  f3/f4/f5 have 256/512/1024 channels.  fp32 only."""
+    moving_variance`; no biases.  f3/f4/f5 have 256/512/1024 channels."""
     model_name = "fcn_8_mobilenet"
     _arch = _lib.ARCH_FCN8_MOBILENET
     _enc_layers = _MOBILENET_LAYERS
 
     def __init__(self, n_classes, input_height=224, input_width=224, channels=3, dtype="f32"):
-        if dtype != "f32":
-            raise NotImplementedError("the MobileNet encoder is built in fp32 only")
         super().__init__(n_classes, input_height, input_width, channels, dtype)
 
     def intermediate(self, name, n, out="probs", n_points=0):

@@ -154,8 +154,8 @@ int flm_fcn32_forward(flm_stream_t stream, const void* packed_dev, const void* x
  * 145-170; every conv has bias and BatchNorm). */
 enum flm_arch {
   FLM_ARCH_FCN8 = 0, FLM_ARCH_FCN32 = 1, FLM_ARCH_FCN8_VGG = 2, FLM_ARCH_FCN32_VGG = 3,
-  FLM_ARCH_FCN8_MOBILENET = 4, FLM_ARCH_FCN32_MOBILENET = 5, /* fp32 only */
-  FLM_ARCH_FCN8_RESNET50 = 6, FLM_ARCH_FCN32_RESNET50 = 7    /* fp32 only */
+  FLM_ARCH_FCN8_MOBILENET = 4, FLM_ARCH_FCN32_MOBILENET = 5,
+  FLM_ARCH_FCN8_RESNET50 = 6, FLM_ARCH_FCN32_RESNET50 = 7     /* every architecture builds in fp32 and bf16 */
 };
 typedef struct flm_fcn_params {
   const flm_conv_params* enc; /* host array of n_enc entries (the pointers inside are device pointers) */

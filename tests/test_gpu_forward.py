@@ -293,8 +293,28 @@ def test_mobilenet_variants(flm):
         got = model.forward_device(torch.from_numpy(img).cuda(), "probs").cpu().numpy()
         assert got.shape == exp.shape
         assert np.abs(got - exp).max() <= 1e-5, (name, np.abs(got - exp).max())
-    with pytest.raises(NotImplementedError):
-        LANDMARKS_MODELS["fcn_8_mobilenet"](68, dtype="bf16")
+
+
+def test_mobilenet_bf16_close_to_fp32(flm):
+    """bf16 MobileNet encoder: bf16 stem / depthwise kernels, pointwise convs on the bf16 implicit GEMM.  The
+    32-channel pointwise conv of block 1 runs on pixel pairs against a block-diagonal filter (flm_pack.hip)."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_mobilenet_weights
+    rng = np.random.default_rng(37)
+    for name, fcn32, (n, h, w) in (("fcn_8_mobilenet", False, (2, 224, 224)), ("fcn_32_mobilenet", True, (1, 64, 96)),
+                                   ("fcn_8_mobilenet", False, (3, 96, 160))):
+        params = synth_mobilenet_weights(68, seed=5, fcn32=fcn32)
+        xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        out = {}
+        for dtype in ("f32", "bf16"):
+            model = LANDMARKS_MODELS[name](68, input_height=h, input_width=w, dtype=dtype)
+            model.load_weights(params)
+            out[dtype] = model.forward_device(xd, "probs").cpu().numpy()
+        assert np.isfinite(out["bf16"]).all()
+        assert np.abs(out["bf16"].sum(-1) - 1).max() < 1e-5
+        d = np.abs(out["bf16"] - out["f32"])
+        print(name, (n, h, w), "bf16 vs fp32 probs: max %.3g mean %.3g" % (d.max(), d.mean()))
+        assert d.mean() < 2e-3 and d.max() < 0.2, (name, d.max(), d.mean())
 
 
 def test_resnet50_variants(flm):

@@ -14,8 +14,6 @@ synth = {"fcn_8": lambda: W.synth_fcn8_weights(68, 2), "fcn_32": lambda: W.synth
          "fcn_8_resnet50": lambda: W.synth_resnet50_weights(68, 2), "fcn_32_resnet50": lambda: W.synth_resnet50_weights(68, 2, fcn32=True)}
 for name, mk in synth.items():
     for dtype in ("f32", "bf16"):
-        if dtype == "bf16" and "mobilenet" in name:
-            continue
         m = LANDMARKS_MODELS[name](68, input_height=256, input_width=256, dtype=dtype)
         m.load_weights(mk())
         for _ in range(2):
