@@ -178,6 +178,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::igemm_bf16_big_enable(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "bf16_lds_dma")) {  // 256x256 tiles: operands by buffer_load ... lds (1) or through registers (0)
+    flm::igemm_bf16_big_dma(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "landmark_candidates")) {  // 0: always materialise the probabilities and decode them
     g_cand_enable = value != 0;
     return FLM_OK;

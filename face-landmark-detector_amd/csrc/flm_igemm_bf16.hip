@@ -45,7 +45,20 @@ constexpr int ROWB = 128;  // bytes of one operand row per k-step
 constexpr unsigned kOobOffset = 0x80000000u;
 constexpr int kSrdFlags = 0x00020000;  // raw dword buffer, gfx9 DATA_FORMAT field
 
-template <int MMAP, bool RELU, int WM, int WN, int TM, int TN>
+// LDS-DMA: buffer_load_dwordx4 ... lds writes lane l's 16 bytes to LDS address M0 + 16*l, no VGPR destination.
+typedef int dma_srd __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_srd dma_make_srd(const void* base) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  return (dma_srd){(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), 0x7fffffff, kSrdFlags};
+}
+__device__ __forceinline__ void dma_load16(dma_srd srd, unsigned lds_addr, unsigned voffset, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voffset), "s"(srd), "s"(soffset)
+               : "memory");
+}
+
+template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA>
 __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmArgs a) {
   constexpr int BMt = WM * TM * 32, BNt = WN * TN * 32, NTHR = WM * WN * 64;
   constexpr int RPT = NTHR / 8;                 // rows one staging pass of the workgroup covers
@@ -103,7 +116,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
     const int m0 = mt * BMt;
 
     // ---- staging role: rows r0 + RPT*j, 16-byte chunk c8 ------------------------------------------------
-    const int c8 = tid & 7, r0 = tid >> 3;
+    // DMA: the loads write LDS themselves, lane l of a wave at byte 16*l of the wave's 1 KiB piece (8 rows): the
+    // XOR swizzle moves to the source side -- the lane at physical chunk tid&7 fetches the logical chunk that lives there
+    const int c8 = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7), r0 = tid >> 3;
     int pyx[AR];  // (py << 16) | px of the filter centre in input coordinates; py = 0x7000 for rows past M
     unsigned rowoff[AR];
 #pragma unroll
@@ -264,6 +279,70 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
     }                                                                                                    \
   }
 
+    // LDS-DMA form of the step (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  Tile t+2 is
+    // requested during slice 3 of step t, straight into the stage whose last fragment reads the barrier of this step
+    // has just retired, and must have landed by the barrier of step t+1 (its vmcnt(0)): three slices of cover.
+    // Written as inline assembly: hipcc orders every ds_read behind a pending LDS-DMA of its own (s_waitcnt vmcnt(0)
+    // before each fragment read -- the requests would land one by one); the assembly is opaque to that bookkeeping
+    // and the one wait that is needed, vmcnt(0) ahead of the step's barrier, is written out.
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned dma_base = (unsigned)(size_t)((lds_char*)smem) + __builtin_amdgcn_readfirstlane(wave) * 8 * ROWB;
+    const dma_srd xdma = dma_make_srd(reinterpret_cast<const char*>(a.x) - xbias);
+    const dma_srd wdma = dma_make_srd(reinterpret_cast<const char*>(a.wt) + (size_t)n0 * a.K * 2);
+#define FLM_DMA_A(J, STG)                                                                             \
+  {                                                                                                   \
+    const int iy = (pyx[J] >> 16) + ld_ky, ix = (pyx[J] & 0xffff) + ld_kx;                            \
+    const bool ok_ = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;                   \
+    dma_load16(xdma, dma_base + (STG) * STAGE + (J) * RPT * ROWB, ok_ ? rowoff[J] : kOobOffset, ld_delta); \
+  }
+#define FLM_DMA_B(J, STG) \
+  dma_load16(wdma, dma_base + (STG) * STAGE + A_BYTES + (J) * RPT * ROWB, wrow0, (J) * wstep + ld_koff);
+#define FLM_DMA_STEP(BUF)                                                                                \
+  {                                                                                                      \
+    FLM_TILE_PARAMS()                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
+      const int nstage = (s < 3) ? (BUF) : ((BUF) ^ 1);                                                  \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+          const int slot = (s * TM + i) * TN + j;                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),          \
+                                                              __builtin_bit_cast(bf16x8, bfr[s & 1][j]), acc[i][j], 0, 0, 0); \
+          if (i == 0)                                                                                    \
+            bfr[(s + 1) & 1][j] = *reinterpret_cast<const float4*>(smem + nstage * STAGE + fbrow + j * 32 * ROWB + fc[(s + 1) & 3]); \
+          if (j == TN - 1)                                                                               \
+            af[i] = *reinterpret_cast<const float4*>(smem + nstage * STAGE + farow + i * 32 * ROWB + fc[(s + 1) & 3]);  \
+          _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                              \
+            if (slot == 3 * SL + (k * SL) / NLD) {                                                       \
+              if (k < AR) { FLM_DMA_A((k < AR ? k : 0), BUF) }                                           \
+              else { FLM_DMA_B((k >= AR ? k - AR : 0), BUF) }                                            \
+            }                                                                                            \
+          }                                                                                              \
+          if (slot == 3 * SL - 1) {                                                                      \
+            __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): this wave's pieces of the next tile are in LDS */ \
+            __syncthreads();                                                                             \
+          }                                                                                              \
+          __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+    if (DMA) {
+      if (nit > 0) {
+        FLM_TILE_PARAMS()
+#pragma unroll
+        for (int j = 0; j < AR; ++j) FLM_DMA_A(j, 0)
+#pragma unroll
+        for (int j = 0; j < BR; ++j) FLM_DMA_B(j, 0)
+        FLM_TILE_PARAMS()  // tile 1 (past the end: tile 0 again, never read)
+#pragma unroll
+        for (int j = 0; j < AR; ++j) FLM_DMA_A(j, 1)
+#pragma unroll
+        for (int j = 0; j < BR; ++j) FLM_DMA_B(j, 1)
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+    } else
     // prologue: tile 0 -> set 0 -> stage 0; tile 1 -> set 1 (written to stage 1 during step 0)
     if (nit > 0) {
       FLM_ST_A()
@@ -282,16 +361,27 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
 #pragma unroll
       for (int j = 0; j < BR; ++j) FLM_LOAD_B(j)
     }
-    __syncthreads();
+    if (!DMA) __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(smem + farow + i * 32 * ROWB + fc[0]);
 #pragma unroll
     for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const float4*>(smem + fbrow + j * 32 * ROWB + fc[0]);
 
-    for (int it = 0; it < nit; it += 2) {
-      FLM_BIG_STEP(0, 1, 0)
-      if (it + 1 < nit) FLM_BIG_STEP(1, 0, 1)
+    if (DMA) {
+      for (int it = 0; it < nit; it += 2) {
+        FLM_DMA_STEP(0)
+        if (it + 1 < nit) FLM_DMA_STEP(1)
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the requests past the last tile still write LDS
+    } else {
+      for (int it = 0; it < nit; it += 2) {
+        FLM_BIG_STEP(0, 1, 0)
+        if (it + 1 < nit) FLM_BIG_STEP(1, 0, 1)
+      }
     }
+#undef FLM_DMA_A
+#undef FLM_DMA_B
+#undef FLM_DMA_STEP
 
 #undef FLM_TILE_PARAMS
 #undef FLM_LOAD_A
@@ -359,13 +449,16 @@ static int g_group_n = 0;     // weight panels per tile group (0: default)
 void igemm_bf16_big_enable(int on) { g_big_enable = on; }
 void igemm_bf16_group_n(int gn) { g_group_n = gn; }
 
-template <int MMAP, bool RELU, int WM, int WN, int TM, int TN>
-static int launch_big(hipStream_t s, IgemmArgs a) {
+static int g_big_dma = 1;  // operands reach LDS by buffer_load ... lds (256x256 tiles); 0: through staging registers
+void igemm_bf16_big_dma(int on) { g_big_dma = on; }
+
+template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA>
+static int launch_big_t(hipStream_t s, IgemmArgs a) {
   constexpr int BMt = WM * TM * 32, BNt = WN * TN * 32;
   constexpr size_t lds = 2 * (size_t)(BMt + BNt) * ROWB + 64;
   static bool attr_done = false;
   if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN>),
+    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
@@ -376,9 +469,15 @@ static int launch_big(hipStream_t s, IgemmArgs a) {
   if (a.gn > a.ntiles) a.gn = a.ntiles;
   a.gm = 32 / a.gn > 0 ? 32 / a.gn : 1;
   const int nblk = cdiv(a.mtiles, a.gm) * a.gm * cdiv(a.ntiles, a.gn) * a.gn;
-  igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN><<<nblk, WM * WN * 64, lds, s>>>(a);
+  igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA><<<nblk, WM * WN * 64, lds, s>>>(a);
   FLM_LAUNCH_CHECK("igemm_bf16_big_kernel");
   return 1;
+}
+
+template <int MMAP, bool RELU, int WM, int WN, int TM, int TN>
+static int launch_big(hipStream_t s, const IgemmArgs& a) {
+  if (WM == 2 && g_big_dma) return launch_big_t<MMAP, RELU, WM, WN, TM, TN, (WM == 2)>(s, a);
+  return launch_big_t<MMAP, RELU, WM, WN, TM, TN, false>(s, a);
 }
 
 template <int WM, int WN, int TM, int TN>

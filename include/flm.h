@@ -191,6 +191,8 @@ int flm_profile_filter(const char* layer);
  * read at launch time; meant for A/B runs (tools/tune.py) and for tests that force a code path:
  *   "bf16_big_tiles"        0 off | 1 auto (default) | 2 whenever the shape allows | 3 auto + 256x128 tiles
  *                           256-row bf16 implicit-GEMM tiles (csrc/flm_igemm_bf16.hip)
+ *   "bf16_lds_dma"          1 (default): the 256x256 tiles fetch their operands with buffer_load ... lds (no staging
+ *                           registers, no LDS write pass); 0: global -> registers -> LDS
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
  *   "landmark_candidates"   0: FLM_OUT_LANDMARKS always materialises the probabilities and decodes them;

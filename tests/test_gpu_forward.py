@@ -190,16 +190,20 @@ def test_bf16_256_row_tiles_equal_128_row_tiles(flm, weights68):
         xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
         outs = {}
         try:
-            for mode in (0, 2):
+            # 0: 128x128 tiles; (2, 0): 256-row tiles staged through registers; (2, 1): filled by LDS-DMA
+            for mode, dma in ((0, 0), (2, 0), (2, 1)):
                 _lib.check(lib.flm_set_tuning(b"bf16_big_tiles", mode), "set_tuning")
+                _lib.check(lib.flm_set_tuning(b"bf16_lds_dma", dma), "set_tuning")
                 probs = model.forward_device(xd, "probs").cpu().numpy()
                 inter = {k: model.intermediate(k, n, "probs").cpu().numpy() for k in ("f2", "f3", "f4", "f5", "fc6", "fc7")}
-                outs[mode] = (probs, inter)
+                outs[(mode, dma)] = (probs, inter)
         finally:
             _lib.check(lib.flm_set_tuning(b"bf16_big_tiles", 1), "set_tuning")
-        for k in outs[0][1]:
-            assert np.array_equal(outs[0][1][k], outs[2][1][k]), (k, n, h, w)
-        assert np.array_equal(outs[0][0], outs[2][0])
+            _lib.check(lib.flm_set_tuning(b"bf16_lds_dma", 1), "set_tuning")
+        for key in ((2, 0), (2, 1)):
+            for k in outs[(0, 0)][1]:
+                assert np.array_equal(outs[(0, 0)][1][k], outs[key][1][k]), (k, key, n, h, w)
+            assert np.array_equal(outs[(0, 0)][0], outs[key][0]), key
 
 
 def test_bf16_halo_conv_equals_implicit_gemm(flm, weights68):
