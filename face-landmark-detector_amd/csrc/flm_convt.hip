@@ -102,6 +102,26 @@ __device__ __forceinline__ float max_raw(float a, float b) {
   return r;
 }
 
+// Reductions over the four lane groups q = lane >> 4 (the 16*MT result rows of one pixel sit in lanes r, r+16, r+32,
+// r+48).  v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- and 32-lane rows between two registers in the
+// VALU: with the same value in both, {dst, src} come back as {[x0,x0,x2,x2], [x1,x1,x3,x3]} and {[lo,lo], [hi,hi]},
+// so one swap + one max / add is the xor-16 / xor-32 butterfly step -- no ds_bpermute round trip, no lane-index
+// arithmetic, no lgkmcnt(0) that would also drain the weight-fragment reads in flight.  Same operand pairs as the
+// xor shuffles they replace (a + b in one lane, b + a in its partner): same bits.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float reduce_q_max(float v) {
+  u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = max_raw(__uint_as_float(t.x), __uint_as_float(t.y));
+  t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max_raw(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ float reduce_q_sum(float v) {
+  u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(t.x) + __uint_as_float(t.y);
+  t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
+
 // MODE: 0 = epilogues 0/1/2 (maps), 1 = epilogue 3 (top-n candidates), 2 = epilogue 4 (sampling launch: wave maxima)
 template <int MT, int G, bool BF, int NT, int MODE, bool SHARE>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
@@ -300,8 +320,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         mx = max3_raw(mx, x0, x1);                                                                \
         mx = max3_raw(mx, x2, x3);                                                                \
       }                                                                                           \
-      mx = max_raw(mx, __shfl_xor(mx, 16));                                                       \
-      mx = max_raw(mx, __shfl_xor(mx, 32));                                                       \
+      mx = reduce_q_max(mx);                                                                      \
       const float nmxl = -mx * 1.44269504088896340736f;                                           \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
         pv[nt][m][e] = FLM_CVALID(m, e) ? softmax_exp<BF>(pv[nt][m][e], mx, nmxl) : 0.f;          \
@@ -314,8 +333,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       float sum = 0.f;                                                                            \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
         sum += pv[nt][m][e];                                                                      \
-      sum += __shfl_xor(sum, 16);                                                                 \
-      sum += __shfl_xor(sum, 32);                                                                 \
+      sum = reduce_q_sum(sum);                                                                    \
       float rs = BF ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;                                    \
       if (CAND && a.epilogue == 3) {                                                              \
         const int ph_ = FLM_PHASE(epi_b0);                                                        \
