@@ -27,7 +27,7 @@ EXPORTS = [
     "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_filter", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
     "flm_decode_workspace_bytes", "flm_decode",
-    "flm_similarity_from_landmarks", "flm_warp_affine", "flm_crop_resize",
+    "flm_similarity_from_landmarks", "flm_similarity_from_landmarks_scaled", "flm_warp_affine", "flm_crop_resize",
 ]
 
 
@@ -113,6 +113,8 @@ def _declare(lib):
     lib.flm_decode.argtypes = [vp, vp, i, i, i, i, i, i, f, vp, vp, sz]
     lib.flm_similarity_from_landmarks.restype = i
     lib.flm_similarity_from_landmarks.argtypes = [vp, vp, vp, i, i, vp]
+    lib.flm_similarity_from_landmarks_scaled.restype = i
+    lib.flm_similarity_from_landmarks_scaled.argtypes = [vp, vp, vp, i, i, C.c_double, C.c_double, vp]
     lib.flm_warp_affine.restype = i
     lib.flm_warp_affine.argtypes = [vp, vp, i, i, i, i, vp, vp, i, i]
     lib.flm_crop_resize.restype = i

@@ -43,8 +43,10 @@ def canonical_template(n_landmarks: int, out_h: int, out_w: int) -> np.ndarray:
     return pts * np.array([out_w - 1, out_h - 1], np.float64)
 
 
-def similarity_device(landmarks, template):
-    """landmarks: CUDA float64 [N,K,2]; template: CUDA float64 [K,2] -> CUDA float32 [N,2,3]."""
+def similarity_device(landmarks, template, landmark_scale=(1.0, 1.0)):
+    """landmarks: CUDA float64 [N,K,2]; template: CUDA float64 [K,2] -> CUDA float32 [N,2,3].
+    `landmark_scale` (sx, sy) takes the landmarks to the template's pixel units inside the kernel (float64
+    products; the decode's reject marker (-1,-1) stays negative, so the fit skips those points)."""
     import torch
     lib = _lib.load()
     n, k, _ = landmarks.shape
@@ -53,9 +55,11 @@ def similarity_device(landmarks, template):
     if tuple(template.shape) != (k, 2):
         raise ValueError("template must be [K,2]")
     m = torch.empty((n, 2, 3), dtype=torch.float32, device=landmarks.device)
-    _lib.check(lib.flm_similarity_from_landmarks(_lib.stream_ptr(), _lib.ptr(landmarks.contiguous()),
-                                                 _lib.ptr(template.contiguous()), n, k, _lib.ptr(m)),
-               "flm_similarity_from_landmarks")
+    _lib.check(lib.flm_similarity_from_landmarks_scaled(_lib.stream_ptr(), _lib.ptr(landmarks.contiguous()),
+                                                        _lib.ptr(template.contiguous()), n, k,
+                                                        float(landmark_scale[0]), float(landmark_scale[1]),
+                                                        _lib.ptr(m)),
+               "flm_similarity_from_landmarks_scaled")
     return m
 
 
@@ -76,11 +80,5 @@ def warp_device(src, m, out_h, out_w, out=None):
 
 def align_device(crops, landmarks_in, template, out_h, out_w, landmark_scale=(1.0, 1.0)):
     """crops [N,H,W,3] + landmarks (crop pixel units after `landmark_scale`) -> aligned crops, M."""
-    import torch
-    lm = landmarks_in
-    if landmark_scale != (1.0, 1.0):
-        lm = landmarks_in * torch.tensor(landmark_scale, dtype=torch.float64, device=lm.device)
-        # keep the decode's reject marker (-1,-1) negative so the fit skips those points
-        lm = torch.where(landmarks_in < 0, landmarks_in, lm)
-    m = similarity_device(lm, template)
+    m = similarity_device(landmarks_in, template, landmark_scale)
     return warp_device(crops, m, out_h, out_w), m

@@ -658,7 +658,16 @@ int flm_similarity_from_landmarks(flm_stream_t stream, const double* lm, const d
     set_error("flm_similarity_from_landmarks: null argument");
     return FLM_ERR_ARG;
   }
-  return launch_similarity(static_cast<hipStream_t>(stream), lm, tmpl, n, k, m);
+  return launch_similarity(static_cast<hipStream_t>(stream), lm, tmpl, n, k, 1.0, 1.0, m);
+}
+
+int flm_similarity_from_landmarks_scaled(flm_stream_t stream, const double* lm, const double* tmpl, int n, int k,
+                                         double sx, double sy, float* m) {
+  if (!lm || !tmpl || !m) {
+    set_error("flm_similarity_from_landmarks_scaled: null argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_similarity(static_cast<hipStream_t>(stream), lm, tmpl, n, k, sx, sy, m);
 }
 
 int flm_warp_affine(flm_stream_t stream, const void* src, int src_is_u8, int n, int hs, int ws, const float* m,

@@ -197,7 +197,7 @@ int launch_cand_merge(hipStream_t s, const unsigned long long* cand, unsigned* c
                       int n_points, float thresh, int cap, double* out);
 
 int launch_preprocess(hipStream_t s, const uint8_t* img, int n, int h, int w, int norm, float* out);
-int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, float* m);
+int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, double sx, double sy, float* m);
 int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, int ws, const float* m, float* dst,
                 int hd, int wd);
 int launch_crop_resize(hipStream_t s, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,

@@ -46,19 +46,29 @@ int launch_preprocess(hipStream_t s, const uint8_t* img, int n, int h, int w, in
 // ---- least-squares similarity (no reflection) from K landmark pairs -----------------------------------
 // Complex form: dst ~ alpha*src + beta, alpha = sum(conj(p')q') / sum|p'|^2 over centred points.
 // Landmarks the decode rejected ((-1,-1), utils/metrics.py:78-79) are left out; fewer than two
-// usable points (or a degenerate cloud) gives the identity.  One thread per face, float64,
-// sequential sums in landmark order.
-__global__ void similarity_kernel(const double* __restrict__ lm, const double* __restrict__ tmpl, int n, int k,
-                                  float* __restrict__ m) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  const double* p = lm + (size_t)f * k * 2;
+// usable points (or a degenerate cloud) gives the identity.  float64, sequential sums in landmark order
+// (oracle/warp_ref.py restates them one by one), so the arithmetic stays with ONE thread per face; the other 63
+// lanes of its wave stage the face's landmarks (times the grid-to-crop scale sx, sy; rejected points keep their
+// negative marker) and the template in LDS, so the serial loops run on LDS latency, not on a global load per term.
+__global__ __launch_bounds__(64) void similarity_kernel(const double* __restrict__ lm, const double* __restrict__ tmpl,
+                                                        int n, int k, double sx, double sy, float* __restrict__ m) {
+  extern __shared__ double sim_s[];  // [k][2] landmarks, [k][2] template
+  const int f = blockIdx.x;
+  double* p = sim_s;
+  double* t = sim_s + 2 * k;
+  for (int i = threadIdx.x; i < 2 * k; i += 64) {
+    const double v = lm[(size_t)f * k * 2 + i];
+    p[i] = v < 0.0 ? v : v * ((i & 1) ? sy : sx);
+    t[i] = tmpl[i];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   double mpx = 0, mpy = 0, mqx = 0, mqy = 0;
   int cnt = 0;
   for (int i = 0; i < k; ++i) {
     if (p[2 * i] < 0.0 || p[2 * i + 1] < 0.0) continue;
     mpx += p[2 * i]; mpy += p[2 * i + 1];
-    mqx += tmpl[2 * i]; mqy += tmpl[2 * i + 1];
+    mqx += t[2 * i]; mqy += t[2 * i + 1];
     ++cnt;
   }
   double a = 1.0, b = 0.0, tx = 0.0, ty = 0.0;
@@ -68,7 +78,7 @@ __global__ void similarity_kernel(const double* __restrict__ lm, const double* _
     for (int i = 0; i < k; ++i) {
       if (p[2 * i] < 0.0 || p[2 * i + 1] < 0.0) continue;
       const double px = p[2 * i] - mpx, py = p[2 * i + 1] - mpy;
-      const double qx = tmpl[2 * i] - mqx, qy = tmpl[2 * i + 1] - mqy;
+      const double qx = t[2 * i] - mqx, qy = t[2 * i + 1] - mqy;
       sa += px * qx + py * qy;
       sb += px * qy - py * qx;
       var += px * px + py * py;
@@ -85,12 +95,12 @@ __global__ void similarity_kernel(const double* __restrict__ lm, const double* _
   o[3] = (float)b; o[4] = (float)a;    o[5] = (float)ty;
 }
 
-int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, float* m) {
-  if (n <= 0 || k <= 0) {
+int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n, int k, double sx, double sy, float* m) {
+  if (n <= 0 || k <= 0 || k > 1024) {
     set_error("similarity: bad sizes n=%d k=%d", n, k);
     return FLM_ERR_SHAPE;
   }
-  similarity_kernel<<<cdiv(n, 64), 64, 0, s>>>(lm, tmpl, n, k, m);
+  similarity_kernel<<<n, 64, sizeof(double) * 4 * k, s>>>(lm, tmpl, n, k, sx, sy, m);
   FLM_LAUNCH_CHECK("similarity_kernel");
   return FLM_OK;
 }

@@ -233,6 +233,11 @@ int flm_decode(flm_stream_t stream, const float* hm_dev, int n, int h, int w, in
 int flm_similarity_from_landmarks(flm_stream_t stream, const double* lm_dev /*[N,K,2]*/,
                                   const double* tmpl_dev /*[K,2]*/, int n, int k,
                                   float* m_dev /*[N,2,3]*/);
+/* Same fit with the landmarks first taken from output-grid to crop pixel units: x * sx, y * sy in float64 (the
+ * reference leaves decoded coordinates in grid units); points the decode rejected, (-1,-1), stay rejected. */
+int flm_similarity_from_landmarks_scaled(flm_stream_t stream, const double* lm_dev /*[N,K,2]*/,
+                                         const double* tmpl_dev /*[K,2]*/, int n, int k, double sx, double sy,
+                                         float* m_dev /*[N,2,3]*/);
 int flm_warp_affine(flm_stream_t stream, const void* src_dev /*[N,Hs,Ws,3]*/, int src_is_u8, int n,
                     int hs, int ws, const float* m_dev /*[N,2,3] src->dst*/,
                     float* dst_dev /*[N,Hd,Wd,3]*/, int hd, int wd);

@@ -74,6 +74,13 @@ def test_similarity_vs_oracle_and_skimage(A, golden_dir):
     got = A.similarity_device(torch.from_numpy(lm).cuda(), torch.from_numpy(tm).cuda()).cpu().numpy()
     np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6)
     assert np.array_equal(got[3], np.array([[1, 0, 0], [0, 1, 0]], np.float32))
+    # grid-to-crop scale applied inside the kernel (float64 products, reject marker kept): the same bits as scaling first
+    sc = (256.0 / 264.0, 250.0 / 264.0)
+    pre = np.where(lm < 0, lm, lm * np.array(sc))
+    a = A.similarity_device(torch.from_numpy(pre).cuda(), torch.from_numpy(tm).cuda()).cpu().numpy()
+    b = A.similarity_device(torch.from_numpy(lm).cuda(), torch.from_numpy(tm).cuda(), sc).cpu().numpy()
+    assert np.array_equal(a, b)
+    np.testing.assert_allclose(b, warp_ref.similarity_ref(pre, tm), rtol=1e-6, atol=1e-6)
     for i in range(4):   # scikit-image's Umeyama estimate on its own points
         g = A.similarity_device(torch.from_numpy(gold["src_pts"][i:i + 1]).cuda(),
                                 torch.from_numpy(gold["dst_pts"][i]).cuda()).cpu().numpy()[0]
