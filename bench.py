@@ -24,6 +24,9 @@ import os
 import sys
 import time
 
+# the pool's host driver only supports dmabuf IPC: RCCL fails with hipIpcGetMemHandle errors without this (set before HIP starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
