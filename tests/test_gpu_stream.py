@@ -132,3 +132,21 @@ def test_batches_beyond_the_launch_limit_are_sliced(setup):
         model.max_batch = saved
     assert torch.equal(whole, sliced)
     assert tuple(cm.shape) == (4, 264, 264)
+
+
+def test_captured_pipeline_equals_eager_sequence(setup):
+    """graphs.CapturedPipeline replays the landmark + alignment launch sequence as one HIP graph: same kernels on the
+    same buffers, so landmarks, matrices and aligned crops equal the eager calls bit for bit, call after call."""
+    from flm_amd import alignment, graphs
+    _, model, _ = setup
+    rng = np.random.default_rng(61)
+    for n in (1, 5):
+        pipe = graphs.CapturedPipeline(model, n, n_points=4)
+        for rep in range(3):
+            crops = torch.from_numpy(rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
+            lm, aligned, m = [t.clone() for t in pipe(crops)]
+            lm_e = model.forward_device(crops, "landmarks", n_points=4)
+            al_e, m_e = alignment.align_device(crops, lm_e, pipe.template, 256, 256, pipe.scale)
+            assert torch.equal(lm, lm_e) and torch.equal(m, m_e) and torch.equal(aligned, al_e), (n, rep)
+        with pytest.raises(ValueError):
+            pipe(torch.zeros((n + 1, 256, 256, 3), dtype=torch.uint8, device="cuda"))
