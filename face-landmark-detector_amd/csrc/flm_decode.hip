@@ -290,23 +290,29 @@ struct CandMergeArgs {
   double* out;
 };
 
-constexpr int kCandClassesPerWave = 5;
+// CPW classes per wave: 5 (a workgroup of four waves covers 17 classes + 3 spare slots, 4 workgroups per face) when
+// the batch fills the chip anyway; 1 (17 workgroups per face) for small batches, where the scan is a serial chain of
+// cnt/64 steps per wave and four workgroups per face leave the chip empty -- every wave still streams all keys of its
+// face, so the finer split multiplies the L2 reads by four: it is chosen only below kCandFineBatch faces.
+constexpr int kCandFineBatch = 32;
 
+template <int CPW>
 __global__ __launch_bounds__(256) void cand_merge_kernel(CandMergeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int face = blockIdx.y;
-  const int cfirst = 17 * blockIdx.x, cend = min(cfirst + 17, a.l);
+  constexpr int CPG = CPW == 1 ? 4 : 17;  // classes per workgroup
+  const int cfirst = CPG * blockIdx.x, cend = min(cfirst + CPG, a.l);
   const unsigned cnt = min(a.cand_cnt[face], (unsigned)a.cap);
   const unsigned long long* src = a.cand + (size_t)face * a.cap;
-  unsigned long long list[kCandClassesPerWave], tau[kCandClassesPerWave];
+  unsigned long long list[CPW], tau[CPW];
 #pragma unroll
-  for (int k = 0; k < kCandClassesPerWave; ++k) { list[k] = 0ull; tau[k] = 0ull; }
+  for (int k = 0; k < CPW; ++k) { list[k] = 0ull; tau[k] = 0ull; }
   for (unsigned i0 = 0; i0 < cnt; i0 += 64) {
     const unsigned long long key = (i0 + lane < cnt) ? src[i0 + lane] : 0ull;
     const int cls = (int)((key >> 17) & 127u);
     const unsigned long long stripped = (key & 0xffffffff00000000ull) | (key & 0x1ffffull);
 #pragma unroll
-    for (int k = 0; k < kCandClassesPerWave; ++k) {
+    for (int k = 0; k < CPW; ++k) {
       const int c = cfirst + wave + 4 * k;
       if (c < cend) {  // wave-uniform
         const unsigned long long cand = (key != 0ull && cls == c) ? stripped : 0ull;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void cand_merge_kernel(CandMergeArgs a) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < kCandClassesPerWave; ++k) {
+  for (int k = 0; k < CPW; ++k) {
     const int c = cfirst + wave + 4 * k;
     if (c < cend) {
       // fewer than n keys: the threshold did not have n pixels above it (or the class has fewer than n non-zero
@@ -384,7 +390,8 @@ int launch_cand_merge(hipStream_t s, const unsigned long long* cand, unsigned* c
   CandMergeArgs a;
   a.cand = cand; a.cand_cnt = cand_cnt; a.n = n; a.w = w; a.l = l; a.n_points = n_points; a.cap = cap;
   a.thresh = thresh; a.out = out;
-  cand_merge_kernel<<<dim3(4, n), 256, 0, s>>>(a);
+  if (n < kCandFineBatch) cand_merge_kernel<1><<<dim3(17, n), 256, 0, s>>>(a);
+  else cand_merge_kernel<5><<<dim3(4, n), 256, 0, s>>>(a);
   FLM_LAUNCH_CHECK("cand_merge_kernel");
   return FLM_OK;
 }
