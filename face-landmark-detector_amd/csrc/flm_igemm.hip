@@ -86,10 +86,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   int pair_mt[2] = {mslot, mslot};
   if (MMAP == 2) {
     // rank the tiles by work, heaviest first (ties by index); LDS scratch = the still unused A buffer
-    int* wk = reinterpret_cast<int*>(As);
+    // tap masks of all tiles, one (tile, position) pair per thread and round: a tile spans up to BM/n + 1 positions
+    // -- every one of the map at a single face -- and a lone thread walking positions x taps of its tile cost 100 us
+    // of the 180 us this layer took at one face
+    unsigned long long* tmask = reinterpret_cast<unsigned long long*>(As);
+    int* wk = reinterpret_cast<int*>(tmask + a.mtiles);
     int* ord = wk + a.mtiles;
-    for (int t = tid; t < a.mtiles; t += 256)
-      wk[t] = __builtin_popcountll(posmajor_tapmask(t, a.M, a.n, a.h, a.w, a.kh, a.kw, a.pad));
+    for (int t = tid; t < a.mtiles; t += 256) tmask[t] = 0ull;
+    __syncthreads();
+    const int npp = (BM - 1) / a.n + 2;
+    for (int idx = tid; idx < a.mtiles * npp; idx += 256) {
+      const int t = idx / npp, m_lo = t * BM, m_hi = (m_lo + BM < a.M ? m_lo + BM : a.M) - 1;
+      const int p = m_lo / a.n + (idx - t * npp);
+      if (p <= m_hi / a.n) atomicOr(&tmask[t], posmajor_posmask(p, a.h, a.w, a.kh, a.kw, a.pad));
+    }
+    __syncthreads();
+    for (int t = tid; t < a.mtiles; t += 256) wk[t] = __builtin_popcountll(tmask[t]);
     __syncthreads();
     for (int t = tid; t < a.mtiles; t += 256) {
       const int wt = wk[t];
@@ -156,12 +168,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const unsigned tm_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tapmask >> 32));
     tapmask = ((unsigned long long)tm_hi << 32) | (unsigned long long)tm_lo;
   }
-  int chunk_first = 0, chunk_end = a.cpt;
-  if (a.ksplit > 1) {  // split-K: blockIdx.y owns a contiguous range of channel chunks
-    chunk_first = (int)blockIdx.y * a.cpt / a.ksplit;
-    chunk_end = ((int)blockIdx.y + 1) * a.cpt / a.ksplit;
+  // k-steps of this tile in iteration order (chunk-major, valid taps inner).  Split-K: blockIdx.y owns a contiguous
+  // range of the DENSE (chunk, tap) sequence -- whole chunks whenever the slice count divides the chunks per tap; bf16
+  // fc6 (4 chunks per tap, 8 slices) is cut inside its chunks -- and runs the valid taps inside it.  Cutting the dense
+  // sequence (not the tile's own list of valid steps) keeps the partition of every output's sum independent of which
+  // taps its tile may skip, i.e. of the batch the face sits in.
+  const int ntv = __builtin_popcountll(tapmask);
+  int nit = ntv * a.cpt, chunk0 = 0;
+  unsigned long long rem0 = tapmask;
+  if (a.ksplit > 1) {
+    const int dense = ntaps * a.cpt;
+    const int d0 = (int)blockIdx.y * dense / a.ksplit, d1 = ((int)blockIdx.y + 1) * dense / a.ksplit;
+    const int c0 = d0 / ntaps, t0 = d0 - c0 * ntaps, c1 = d1 / ntaps, t1 = d1 - c1 * ntaps;
+    const unsigned long long from0 = tapmask & (~0ull << t0);       // taps >= t0
+    const unsigned long long upto1 = tapmask & ((1ull << t1) - 1);  // taps < t1
+    if (c0 == c1) {
+      rem0 = from0 & upto1;
+      nit = __builtin_popcountll(rem0);
+    } else {
+      rem0 = from0;
+      nit = __builtin_popcountll(from0) + (c1 - c0 - 1) * ntv + __builtin_popcountll(upto1);
+    }
+    chunk0 = c0;
+    if (rem0 == 0ull) {  // no valid tap left in the first chunk of the range
+      rem0 = tapmask;
+      ++chunk0;
+    }
   }
-  const int nit = __builtin_popcountll(tapmask) * (chunk_end - chunk_first);
 
   // per-row BYTE offset of the centre pixel; per-tap displacement is wave-uniform
   unsigned rowoff[4];
@@ -192,9 +225,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   ra0Q = ra1Q = ra2Q = ra3Q = rb0Q = rb1Q = rb2Q = rb3Q = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // iterator over (valid tap, channel chunk): state of the NEXT tile to load
-  unsigned long long rem = tapmask;
+  unsigned long long rem = rem0;
+  int cur_chunk = chunk0 < a.cpt ? chunk0 : 0;
   int cur_tap = __builtin_ctzll(rem);
-  int cur_chunk = chunk_first;
   int ld_ky = 0, ld_kx = 0, ld_delta = 0, ld_koff = 0, ld_c0 = 0;
 
 #define FLM_TILE_PARAMS()                                                    \
@@ -210,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     rem &= rem - 1;                                                          \
     if (rem == 0) {                                                          \
       rem = tapmask;                                                         \
-      if (++cur_chunk == chunk_end) cur_chunk = chunk_first;                 \
+      if (++cur_chunk == a.cpt) cur_chunk = 0; /* (past the slice's end: loads nobody uses) */ \
     }                                                                        \
     cur_tap = __builtin_ctzll(rem);                                          \
   }
@@ -547,7 +580,13 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
       (d.kh * d.kw == 1 ? a.cpt >= 32 : (d.pool ? a.cpt >= 8 : a.cpt >= 4)) && (d.relu != 2 || d.pool)) {
     int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
     const int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
-    if (ks > a.cpt / per) ks = a.cpt / per;
+    if (d.cout >= 1024 && d.kh * d.kw > 1) {
+      // fc6: the slices cut its 49 x 8 (bf16: 49 x 4) steps of the dense (chunk, tap) sequence, not whole chunks --
+      // with 4 chunks per tap half of the 8 bf16 slices had nothing to do.  (16 slices measured no faster than 8.)
+      if (ks > d.kh * d.kw * a.cpt / 8) ks = d.kh * d.kw * a.cpt / 8;
+    } else if (ks > a.cpt / per) {
+      ks = a.cpt / per;
+    }
     if (ks > 1 && (size_t)ks * a.M * d.ldc * sizeof(float) <= d.splitk_ws_bytes) {
       a.ksplit = ks;
       a.part = d.splitk_ws;

@@ -45,6 +45,18 @@ __device__ __forceinline__ unsigned long long posmajor_tapmask(int t, int M, int
   return mask;
 }
 
+// Taps that see an in-bounds pixel from position p = y*w + x alone: rows ky of kx_lo..kx_hi.
+__device__ __forceinline__ unsigned long long posmajor_posmask(int p, int h, int w, int kh, int kw, int pad) {
+  const int y = p / w, x = p - y * w;
+  const int kx_lo = pad - x > 0 ? pad - x : 0, kx_hi = pad + w - 1 - x < kw - 1 ? pad + w - 1 - x : kw - 1;
+  const int ky_lo = pad - y > 0 ? pad - y : 0, ky_hi = pad + h - 1 - y < kh - 1 ? pad + h - 1 - y : kh - 1;
+  if (kx_hi < kx_lo) return 0ull;
+  const unsigned long long row = ((1ull << (kx_hi - kx_lo + 1)) - 1ull) << kx_lo;
+  unsigned long long mask = 0ull;
+  for (int ky = ky_lo; ky <= ky_hi; ++ky) mask |= row << (ky * kw);
+  return mask;
+}
+
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 // bf16 layers whose tile grid fills the chip with 256-row tiles (flm_igemm_bf16.hip); returns 1 when it launched,
