@@ -573,16 +573,19 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
   // The slice count is a step function of the tile count, the same for fc6 and fc7 (<= 64 tiles, i.e. up to 4
   // faces: 8 slices; up to 8 faces: 4; up to 16: 2): batches inside one bracket sum in the same order, so a face's
-  // result does not depend on its neighbours there.  Pooled 3x3 layers join in when they have 8 chunks per tap (enc4,
-  // enc5: 16 and 4 workgroups for one face); their reduce applies BN / ReLU and the 2x2 max to the summed quads.
+  // result does not depend on its neighbours there.  3x3 encoder layers join in when they have 4 chunks per tap and at
+  // most 16 tiles per face, so that one to four faces share the bracket (enc4, enc5: 16 and 4 workgroups for one face;
+  // enc3 has 64 tiles per face: split at one face and whole at three, its sums would depend on the batch); their reduce applies BN / ReLU and the 2x2 max to the summed quads.
   const int tile_cap = d.cout >= 1024 ? 256 : 64;  // the wide fc layers keep splitting until they fill the chip
   if (d.splitk_ws && !d.res && stride == 1 && tiles <= tile_cap && (!d.pool || (a.M & 3) == 0) &&
-      (d.kh * d.kw == 1 ? a.cpt >= 32 : (d.pool ? a.cpt >= 8 : a.cpt >= 4)) && (d.relu != 2 || d.pool)) {
+      (d.kh * d.kw == 1 ? a.cpt >= 32 : (a.cpt >= 4 && (d.cout >= 1024 || tiles <= 16 * (d.n > 0 ? d.n : 1)))) &&
+      (d.relu != 2 || d.pool)) {
     int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
     const int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
-    if (d.cout >= 1024 && d.kh * d.kw > 1) {
-      // fc6: the slices cut its 49 x 8 (bf16: 49 x 4) steps of the dense (chunk, tap) sequence, not whole chunks --
-      // with 4 chunks per tap half of the 8 bf16 slices had nothing to do.  (16 slices measured no faster than 8.)
+    if (d.kh * d.kw > 1) {
+      // the slices cut the dense (chunk, tap) sequence, not whole chunks, at least 8 steps each: fc6's 49 x 8 (bf16:
+      // 49 x 4 -- by chunks half of its 8 slices had nothing to do; 16 slices measured no faster than 8); enc3 with
+      // its 9 x 4 steps in fp32 takes 4 slices (one face: 16 workgroups otherwise)
       if (ks > d.kh * d.kw * a.cpt / 8) ks = d.kh * d.kw * a.cpt / 8;
     } else if (ks > a.cpt / per) {
       ks = a.cpt / per;
