@@ -54,7 +54,14 @@ struct ProfScope {
 // fp32 up3 is bound by the matrix pipe and writes its map for free; the gain is the decode).  0 = off (tests, A/B).
 static int g_cand_enable = 1;
 static int g_cand_cap_div = 1;  // > 1 shrinks the per-face list (tests force the overflow fallback with it)
-static int g_cand_sub = 4;      // phases per tile in the sampling launch (R of flm_convt.hip)
+static int g_cand_sub = 0;      // phases per tile in the sampling launch (R of flm_convt.hip); 0: by n_points
+// More sampled phases cost 1/64 of up3 each and tighten the threshold: the key lists shrink about in proportion.  At
+// n = 4 the lists are short anyway (4 phases: 8-10 k keys per face); at n >= 16 their merge costs more than the extra
+// phases (batch 512 bf16, n = 25: 12.1 ms with 4 phases, 11.5 with 8; tools/ab_sub.py).
+static int cand_sub_for(int n_points) {
+  if (g_cand_sub > 0) return g_cand_sub;
+  return n_points <= 8 ? 4 : (n_points <= 15 ? 6 : 8);
+}
 static bool landmark_candidates_enabled(const ConvTGeom& g, int fcn32, int decode_mode, int n_points, int oh, int ow) {
   return g_cand_enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 32 &&
          convt_candidates_supported(g) && (long long)oh * ow < (1 << 17);
@@ -103,7 +110,7 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
     W.decode = take(cur, decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
     if (landmark_candidates_enabled(g, A.fcn32, decode_mode, n_points, W.oh, W.ow)) {
       const int h3 = h / 8, w3 = w / 8;
-      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, g_cand_sub) * 16 * g.MT);  // sampled maxima
+      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, cand_sub_for(n_points)) * 16 * g.MT);  // sampled maxima
       W.tau = take(cur, sizeof(float) * (size_t)n * C);
       // expected keys per class: the n-th of 1/64 of the pixels ranks about 64*n-th overall; x4 head room
       W.cand_cap = (int)align_up((size_t)C * 64 * n_points * 4 / g_cand_cap_div, 64);
@@ -187,8 +194,8 @@ int flm_set_tuning(const char* key, int value) {
     return FLM_OK;
   }
   if (!strcmp(key, "candidate_sub_phases")) {
-    if (value < 1 || value > 16) {
-      set_error("flm_set_tuning: candidate_sub_phases must be in [1,16]");
+    if (value < 0 || value > 16) {
+      set_error("flm_set_tuning: candidate_sub_phases must be in [0,16]");
       return FLM_ERR_ARG;
     }
     g_cand_sub = value;
@@ -556,12 +563,12 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + W.cand);
     FLM_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned) * ((size_t)n + 1), s));
     ConvTDesc ts = t;
-    ts.y = sub; ts.epilogue = 4; ts.sub = g_cand_sub;
+    ts.y = sub; ts.epilogue = 4; ts.sub = cand_sub_for(n_points);
     { ProfScope ps(s, "up3_sub");
     rc = launch_convt(s, ts); }
     if (rc) return rc;
     { ProfScope ps(s, "tau");
-    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, g_cand_sub), 16 * L.g.MT, C,
+    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, cand_sub_for(n_points)), 16 * L.g.MT, C,
                          n_points, tau); }
     if (rc) return rc;
     ConvTDesc tc = t;

@@ -198,7 +198,8 @@ int flm_profile_filter(const char* layer);
  *   "landmark_candidates"   0: FLM_OUT_LANDMARKS always materialises the probabilities and decodes them;
  *                           1 (default): top-n with n <= 32 on the 68-class FCN-8 kernels selects from candidate
  *                           keys emitted by the last transposed conv (bit-identical results, gated fallback)
- *   "candidate_sub_phases"  phases per tile in that path's sampling launch (1..16, default 4)
+ *   "candidate_sub_phases"  phases per tile in that path's sampling launch (1..16; default 0 = by n_points: 4 up to
+ *                           n = 8, 6 up to 15, 8 beyond)
  *   "candidate_cap_div"     shrink the candidate lists by this factor (tests of the overflow fallback)
  * "landmark_candidates" and "candidate_*" change the workspace layout: query flm_*_workspace_bytes after
  * setting them. */

@@ -55,11 +55,12 @@ def test_tuning_knobs_and_workspace_layout():
     from flm_amd import _lib
     lib = _lib.load()
     for key, val in ((b"none", 0), (b"bf16_big_tiles", 1), (b"bf16_group_n", 0), (b"bf16_lds_dma", 1), (b"bf16_conv3_halo", 1),
-                     (b"landmark_candidates", 1), (b"candidate_sub_phases", 4), (b"candidate_cap_div", 1)):
+                     (b"landmark_candidates", 1), (b"candidate_sub_phases", 4), (b"candidate_sub_phases", 0),
+                     (b"candidate_cap_div", 1)):
         assert lib.flm_set_tuning(key, val) == 0, key
     assert lib.flm_set_tuning(b"no_such_knob", 1) != 0 and b"no_such_knob" in lib.flm_last_error()
     assert lib.flm_set_tuning(b"bf16_group_n", 3) != 0
-    assert lib.flm_set_tuning(b"candidate_sub_phases", 0) != 0
+    assert lib.flm_set_tuning(b"candidate_sub_phases", 17) != 0 and lib.flm_set_tuning(b"candidate_sub_phases", -1) != 0
     assert lib.flm_set_tuning(b"candidate_cap_div", 0) != 0
     args = (8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN)
     try:

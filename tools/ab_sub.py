@@ -14,8 +14,8 @@ for dtype, B in (("f32", 64), ("bf16", 512)):
     model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
     model.load_weights(w)
     x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
-    for npts in (4, 25):
-        for sub in (4, 3, 2, 1):
+    for npts in [int(v) for v in os.environ.get("NPTS", "4,25").split(",")]:
+        for sub in [int(v) for v in os.environ.get("SUBS", "4,3,2,1").split(",")]:
             _lib.check(lib.flm_set_tuning(b"candidate_sub_phases", sub), "set_tuning")
             model._ws.clear()
             for _ in range(3):
@@ -33,4 +33,4 @@ for dtype, B in (("f32", 64), ("bf16", 512)):
             cnt = ws[off(b"cand_cnt"):off(b"cand_cnt") + 4 * (B + 1)].view(torch.int32).cpu().numpy()
             print("%s n_points %2d sub %d: %.3f ms  keys/face min %d max %d (cap %d)  fallback %d" %
                   (dtype, npts, sub, 1e3 * dt, cnt[:B].min(), cnt[:B].max(), cap, cnt[B]), flush=True)
-_lib.check(lib.flm_set_tuning(b"candidate_sub_phases", 4), "set_tuning")
+_lib.check(lib.flm_set_tuning(b"candidate_sub_phases", 0), "set_tuning")
