@@ -581,7 +581,11 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
       (d.kh * d.kw == 1 ? a.cpt >= 32 : (a.cpt >= 4 && (d.cout >= 1024 || tiles <= 16 * (d.n > 0 ? d.n : 1)))) &&
       (d.relu != 2 || d.pool)) {
     int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
-    const int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
+    int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
+    if (d.kh * d.kw == 1 && tiles <= 8) {  // score5 up to 16 faces: 1..8 workgroups walking K = 4096 otherwise
+      ks = 32;
+      per = 4;
+    }
     if (d.kh * d.kw > 1) {
       // the slices cut the dense (chunk, tap) sequence, not whole chunks, at least 8 steps each: fc6's 49 x 8 (bf16:
       // 49 x 4 -- by chunks half of its 8 slices had nothing to do; 16 slices measured no faster than 8); enc3 with
