@@ -576,11 +576,16 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   // result does not depend on its neighbours there.  3x3 encoder layers join in when they have 4 chunks per tap and at
   // most 16 tiles per face, so that one to four faces share the bracket (enc4, enc5: 16 and 4 workgroups for one face;
   // enc3 has 64 tiles per face: split at one face and whole at three, its sums would depend on the batch); their reduce applies BN / ReLU and the 2x2 max to the summed quads.
-  const int tile_cap = d.cout >= 1024 ? 256 : 64;  // the wide fc layers keep splitting until they fill the chip
+  // (a 3x3 encoder layer with up to 64 tiles per face -- fp32 enc3 -- splits for one to four faces, always 4 ways:
+  // 16 workgroups x 36 k-steps for one face otherwise)
+  const int faces = d.n > 0 ? d.n : 1;
+  const bool few_faces = d.kh * d.kw > 1 && d.cout < 1024 && faces <= 4 && tiles <= 64 * faces;
+  const int tile_cap = (d.cout >= 1024 || few_faces) ? 256 : 64;  // the wide fc layers keep splitting until they fill the chip
   if (d.splitk_ws && !d.res && stride == 1 && tiles <= tile_cap && (!d.pool || (a.M & 3) == 0) &&
-      (d.kh * d.kw == 1 ? a.cpt >= 32 : (a.cpt >= 4 && (d.cout >= 1024 || tiles <= 16 * (d.n > 0 ? d.n : 1)))) &&
+      (d.kh * d.kw == 1 ? a.cpt >= 32 : (a.cpt >= 4 && (d.cout >= 1024 || tiles <= 16 * faces || few_faces))) &&
       (d.relu != 2 || d.pool)) {
     int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
+    if (few_faces && tiles > 16 * faces) ks = 8;  // (capped to 9 * cpt / 8 below: the same count for 1..4 faces)
     int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
     if (d.kh * d.kw == 1 && tiles <= 8) {  // score5 up to 16 faces: 1..8 workgroups walking K = 4096 otherwise
       ks = 32;

@@ -13,7 +13,7 @@ w = synth_fcn8_weights(68, 2)
 for dtype in ("f32", "bf16"):
     m = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
     m.load_weights(w)
-    for B in (1, 4, 16):
+    for B in [int(v) for v in os.environ.get("BS", "1,4,16").split(",")]:
         x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
         for _ in range(5):
             m.forward_device(x, "landmarks", n_points=4)
