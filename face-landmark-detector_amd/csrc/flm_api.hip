@@ -98,8 +98,8 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
     const size_t fc_bytes = sizeof(float) * 8 * rows * kFc;
     if (fc_bytes > W.splitk_bytes) W.splitk_bytes = fc_bytes;
   }
-  if (n <= 4) {  // a 3x3 layer on the 1/4-resolution grid with 256 outputs (vanilla enc3, fp32) in 4 slices
-    const size_t enc3_bytes = sizeof(float) * 4 * (size_t)n * (h / 4) * (w / 4) * 256;
+  if (n <= 4) {  // a 3x3 layer on the 1/4-resolution grid with 256 outputs (vanilla enc3, fp32) in 4 slices, 4 faces
+    const size_t enc3_bytes = sizeof(float) * 4 * (size_t)4 * (h / 4) * (w / 4) * 256;
     if (enc3_bytes > W.splitk_bytes) W.splitk_bytes = enc3_bytes;
   }
   W.splitk = take(cur, W.splitk_bytes);

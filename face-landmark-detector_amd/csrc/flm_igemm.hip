@@ -599,7 +599,9 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
     } else if (ks > a.cpt / per) {
       ks = a.cpt / per;
     }
-    if (ks > 1 && (size_t)ks * a.M * d.ldc * sizeof(float) <= d.splitk_ws_bytes) {
+    // (few_faces: the decision must not depend on how many of the 1..4 faces are present -- size for four)
+    const size_t part_rows = few_faces ? (size_t)(a.M / faces) * 4 : (size_t)a.M;
+    if (ks > 1 && (size_t)ks * part_rows * d.ldc * sizeof(float) <= d.splitk_ws_bytes) {
       a.ksplit = ks;
       a.part = d.splitk_ws;
     }
