@@ -150,3 +150,26 @@ def test_captured_pipeline_equals_eager_sequence(setup):
             assert torch.equal(lm, lm_e) and torch.equal(m, m_e) and torch.equal(aligned, al_e), (n, rep)
         with pytest.raises(ValueError):
             pipe(torch.zeros((n + 1, 256, 256, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_bf16_faces_do_not_depend_on_their_batch(setup):
+    """The bf16 stack splits K for fc6 / fc7 / enc4 / enc5 at a few faces (dense (chunk, tap) slices): one to four faces
+    share every bracket, so a face's landmarks are the same bits alone, in a ragged batch of three, and in slices."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    _, _, params = setup
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype="bf16")
+    model.load_weights(params)
+    rng = np.random.default_rng(12)
+    crops = torch.from_numpy(rng.integers(0, 256, (4, 256, 256, 3), dtype=np.uint8)).cuda()
+    three = model.forward_device(crops[:3].contiguous(), "landmarks", n_points=4).clone()
+    for i in range(3):
+        one = model.forward_device(crops[i:i + 1].contiguous(), "landmarks", n_points=4)
+        assert torch.equal(three[i], one[0]), i
+    whole = model.forward_device(crops, "landmarks", n_points=4).clone()
+    saved = model.max_batch
+    try:
+        model.max_batch = 2
+        sliced = model.forward_device(crops, "landmarks", n_points=4)
+    finally:
+        model.max_batch = saved
+    assert torch.equal(whole, sliced) and torch.equal(whole[:3], three)
