@@ -293,8 +293,9 @@ struct CandMergeArgs {
 // CPW classes per wave: 5 (a workgroup of four waves covers 17 classes + 3 spare slots, 4 workgroups per face) when
 // the batch fills the chip anyway; 1 (17 workgroups per face) for small batches, where the scan is a serial chain of
 // cnt/64 steps per wave and four workgroups per face leave the chip empty -- every wave still streams all keys of its
-// face, so the finer split multiplies the L2 reads by four: it is chosen only below kCandFineBatch faces.
-constexpr int kCandFineBatch = 32;
+// face, so the finer split multiplies the L2 reads by four: it is chosen only below kCandFineBatch faces (64 faces:
+// 78 -> 56 us; at 512 the coarse split's 0.17 ms would become about 0.4 ms of L2 reads).
+constexpr int kCandFineBatch = 128;
 
 template <int CPW>
 __global__ __launch_bounds__(256) void cand_merge_kernel(CandMergeArgs a) {

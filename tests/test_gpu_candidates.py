@@ -115,11 +115,11 @@ def test_candidate_path_on_a_non_square_input(flm, weights68, dtype):
         got = _landmarks(model, xd, n_points, 0.0, candidates=True)
         assert np.array_equal(got, ref), (dtype, n_points)
     assert ref[..., 0].max() < 168 and ref[..., 1].max() < 104
-    # 33 faces: the key merge switches from one class per wave (small batches) to five (flm_decode.hip)
-    xd = torch.from_numpy(rng.integers(0, 256, (33, 96, 160, 3), dtype=np.uint8)).cuda()
+    # 130 faces: the key merge switches from one class per wave (below 128 faces) to five (flm_decode.hip)
+    xd = torch.from_numpy(rng.integers(0, 256, (130, 96, 160, 3), dtype=np.uint8)).cuda()
     ref = _landmarks(model, xd, 4, 0.0, candidates=False)
     got = _landmarks(model, xd, 4, 0.0, candidates=True)
-    assert np.array_equal(got, ref), (dtype, "33 faces")
+    assert np.array_equal(got, ref), (dtype, "130 faces")
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
