@@ -191,3 +191,32 @@ def test_canonical_template():
     assert len({tuple(np.round(p, 6)) for p in t}) == 68
     assert np.array_equal(t, alignment.canonical_template(68, 256, 256))
     assert alignment.canonical_template(5, 112, 112).shape == (5, 2)
+
+
+def test_bench_cpu_baseline_counts_the_cores_it_may_use(monkeypatch, tmp_path):
+    """bench.usable_cores: affinity mask cut by the cgroup CPU quota (the GPU box grants 16 CPUs of a 256-thread host;
+    sizing the CPU baseline from os.cpu_count() oversubscribed it 16x)."""
+    import builtins
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("flm_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    real_open = builtins.open
+
+    def fake(quota_text):
+        f = tmp_path / "cpu.max"
+        f.write_text(quota_text)
+
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                return real_open(str(f), *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert bench.usable_cores() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert bench.usable_cores() == 64          # no quota: the affinity mask, capped at 64 worker threads
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    assert bench.usable_cores() == 8
