@@ -122,6 +122,21 @@ __device__ __forceinline__ float reduce_q_sum(float v) {
   return __uint_as_float(t.x) + __uint_as_float(t.y);
 }
 
+// Maximum over the 16 lanes r = lane & 15 of one lane group (the wave's 16 pixels of one class), in every lane of the
+// group: four DPP steps in the VALU -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror (after
+// the first two a quad is uniform, so the mirrors pair quads and then halves) -- instead of four ds_bpermute shuffles
+// with their lane-index arithmetic and LDS round trips (34 values per wave and sampled phase).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float reduce_r_max(float v) {
+  v = max_raw(v, dpp_mov<0xB1>(v));
+  v = max_raw(v, dpp_mov<0x4E>(v));
+  v = max_raw(v, dpp_mov<0x141>(v));
+  return max_raw(v, dpp_mov<0x140>(v));
+}
+
 // MODE: 0 = epilogues 0/1/2 (maps), 1 = epilogue 3 (top-n candidates), 2 = epilogue 4 (sampling launch: wave maxima)
 template <int MT, int G, bool BF, int NT, int MODE, bool SHARE>
 __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void convt_kernel(ConvTArgs a) {
@@ -353,11 +368,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       /* class maxima over the wave's 16 pixels (lanes r of one q), then one LDS max per class */  \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int e = 0; e < 4; ++e) \
        if (FLM_CVALID(m, e)) {                                                                    \
-        float v = ovalid ? pv[nt][m][e] : 0.f;                                                    \
-        v = fmaxf(v, __shfl_xor(v, 1));                                                           \
-        v = fmaxf(v, __shfl_xor(v, 2));                                                           \
-        v = fmaxf(v, __shfl_xor(v, 4));                                                           \
-        v = fmaxf(v, __shfl_xor(v, 8));                                                           \
+        float v = reduce_r_max(ovalid ? pv[nt][m][e] : 0.f);                                      \
         if (r == 0) atomicMax(&wmax[(B0) * 16 * MT + 16 * m + 4 * q + e], __float_as_uint(v));     \
       }                                                                                           \
     } else if (CAND) {                                                                            \
