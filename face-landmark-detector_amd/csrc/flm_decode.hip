@@ -49,10 +49,13 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), srclane);
   return ((unsigned long long)hi << 32) | lo;
 }
+// lane i <- lane i-1 across the whole wave, lane 0 <- 0: the gfx9 DPP wave shift (wave_shr:1, one VALU move per half)
+// instead of __shfl_up's ds_bpermute round trip -- this sits on the serial chain of every list insertion.
 __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int lane) {
-  const unsigned lo = __shfl_up((unsigned)v, 1);
-  const unsigned hi = __shfl_up((unsigned)(v >> 32), 1);
-  return lane == 0 ? 0ull : (((unsigned long long)hi << 32) | lo);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+  (void)lane;
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // Insert every key of `cand` (one per lane, 0 = none) that beats the list's n-th entry.
