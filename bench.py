@@ -3,16 +3,19 @@
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--config 4]
 
-One step = one pass of the hot path over one batch of synthetic 256x256 uint8 BGR face crops
-already resident in HBM (BASELINE.json configs[1]: batch 64, fp32):
-    fused preprocess + FCN-8 forward -> softmax probabilities [64, 264*264, 68]
-    -> top-n landmark decode (n=4, thresh=0: the reference's as-shipped decode)
-    -> similarity fit + alignment warp to 256x256
-    -> (N > 1) RCCL all-gather of the landmark tensors.
-Ranks are weak-scaled: every rank runs its own batch (no data-path collective besides the
-landmark gather).  Prints ONE JSON line on rank 0.
+One step = one pass of the hot path over one batch of synthetic 256x256 uint8 BGR face crops already resident in HBM:
+    fused preprocess + FCN-8 forward -> softmax -> top-n landmark decode (n=4, thresh=0: the reference's as-shipped
+    decode) -> similarity fit + alignment warp to 256x256 -> (N > 1) RCCL all-gather of the landmark tensors.
+
+--config 2 (default)  BASELINE.json configs[1]: 64 faces per GPU, fp32 -- the headline (`value`, dtype "f32").
+                      At N = 1 the line also carries: cpu_baseline, parity, the bf16 configs[2] run with its own roofline
+                      block, and HBM-bound kernel entries.  At N > 1 it also carries `config4` (below) as a side object,
+                      so one driver run per N measures both.
+--config 3            BASELINE.json configs[2]: 512 faces, bf16 operands / fp32 accumulate, one GPU, as the headline.
+--config 4            BASELINE.json configs[3]: 512 bf16 faces per GPU (4096 at 8) + all-gather, as the headline.
+Ranks are weak-scaled: every rank runs its own batch; the only collective is the landmark gather.  ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -21,6 +24,7 @@ import concurrent.futures
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,15 +35,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GFLOP_PER_FACE = 17.844          # 2*MAC over every Conv2D/Conv2DTranspose, dense
-FC6_GFLOP_PER_FACE = 6.5767      # fc6 7x7x256x4096 on 8x8, dense count (includes zero-padded taps)
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = FP32 vector peak
 PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+DECODE_BYTES_PER_FACE = 18957312 + 544     # fp32 [264,264,68] read + [68,2] f32-sized written
+WARP_BYTES_PER_FACE = 196608 + 786432      # u8 source + f32 destination
+
+
+# ---- work accounting ---------------------------------------------------------------------------------------------
+def _same_conv_fraction(size, k):
+    """Fraction of the k x k taps of a 'same' convolution on a size x size map that fall on real pixels."""
+    pad = k // 2
+    valid = sum(sum(1 for t in range(k) if 0 <= y + t - pad < size) for y in range(size))
+    return (valid / (size * k)) ** 2
+
+
+def layer_work(h=256, c=68):
+    """{layer: (dense, useful)} GFLOP per face, 2*MAC.  dense = SURVEY 8(d)'s count (zero-padded taps included: 17.844
+    in total); useful = the same without the products whose activation operand is zero padding (fc6's 7x7 'same' on
+    8x8: 61.7 %; the 3x3 layers: 91.8-99.5 %).  `roofline.frac` prices USEFUL work: a kernel that skips padding taps
+    (fc6 does) must not read above 1."""
+    g = {}
+    chans = [(3, 64), (64, 128), (128, 256), (256, 256), (256, 256)]
+    s = h
+    for i, (ci, co) in enumerate(chans):
+        dense = 2.0 * s * s * 9 * ci * co / 1e9
+        g["enc%d" % (i + 1)] = (dense, dense * _same_conv_fraction(s, 3))
+        s //= 2
+    d6 = 2.0 * s * s * 49 * 256 * 4096 / 1e9
+    g["fc6"] = (d6, d6 * _same_conv_fraction(s, 7))
+    for name, k, n in (("fc7", 4096, 4096), ("score5", 4096, c)):
+        g[name] = (2.0 * s * s * k * n / 1e9,) * 2
+    g["score4"] = (2.0 * (2 * s) ** 2 * 256 * c / 1e9,) * 2
+    g["score3"] = (2.0 * (4 * s) ** 2 * 256 * c / 1e9,) * 2
+    g["up5"] = (2.0 * s * s * 16 * c * c / 1e9,) * 2
+    g["up4"] = (2.0 * (2 * s) ** 2 * 16 * c * c / 1e9,) * 2
+    g["up3"] = (2.0 * (4 * s) ** 2 * 256 * c * c / 1e9,) * 2
+    return g
+
+
+WORK = layer_work()
+GFLOP_PER_FACE = sum(v[0] for v in WORK.values())          # 17.844
+USEFUL_GFLOP_PER_FACE = sum(v[1] for v in WORK.values())   # 15.18
 
 
 def fc6_issued_gflop(batch):
-    """MACs fc6 actually issues at this batch: position-major 128-row tiles skip the filter taps that see
-    only zero padding for the whole tile (csrc/flm_igemm_f32.hip); returned as 2*MAC in GFLOP."""
+    """MACs the fp32 fc6 actually issues at this batch: position-major 128-row tiles skip the filter taps that see
+    only zero padding for the whole tile (csrc/flm_igemm.hip); returned as 2*MAC in GFLOP."""
     n, h, w, kh, pad, cin, cout = batch, 8, 8, 7, 3, 256, 4096
     m_total = n * h * w
     taps = 0
@@ -58,29 +100,25 @@ def fc6_issued_gflop(batch):
     return 2.0 * taps * 128 * cin * cout / 1e9
 
 
-def load_traffic(layer):
-    """HBM bytes per launch of a layer's kernel from the committed PMC summary (None when absent):
-    profiles/traffic_latest.json = {layer: FETCH_SIZE*2 + WRITE_SIZE in bytes}, see profiles/README.md."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def load_traffic(name, layer):
+    """HBM bytes per launch of a layer's kernel from a COMMITTED PMC summary (None when absent): profiles/<name> =
+    {layer: FETCH_SIZE*2 + WRITE_SIZE in bytes}, see profiles/README.md.  Not measured by this run."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f).get(layer)
     except (OSError, ValueError):
         return None
 
 
-# decode side of the step: the landmark selection ("up3_sub" + "tau" = its threshold pass over a 1/16 sample of the
-# map) and the gated fallback launches; everything else is the FCN forward whose FLOPs SURVEY 8(d) counts
+# decode side of the step: the landmark selection ("up3_sub" + "tau" = its threshold pass over a sample of the map) and
+# the gated fallback launches; everything else is the FCN forward whose FLOPs SURVEY 8(d) counts
 DECODE_KEYS = ("decode", "up3_sub", "tau", "decode_fallback", "up3_fallback")
-
-
 RECORDS_PER_STEP = 24   # launches one step brackets at most
 LAYER_PASS_STEPS = 3    # steps of the separate per-layer timing pass
 
 
 def read_profile(lib):
     """Per-layer mean duration (ms) of the launches recorded since the last reset."""
-    import numpy as np
     layer_ms = {}
     name = C.create_string_buffer(32)
     ms = C.c_float()
@@ -88,62 +126,213 @@ def read_profile(lib):
     while lib.flm_profile_read(i, name, 32, C.byref(ms)) == 0:
         layer_ms.setdefault(name.value.decode(), []).append(ms.value)
         i += 1
-    return {k: float(np.mean(v)) for k, v in layer_ms.items()}
+    return {k: sum(v) / len(v) for k, v in layer_ms.items()}
 
 
-def bf16_config3(lib, dev, batch, steps, warmup, n_points, fp32_model):
-    """BASELINE configs[2]: batch-512 bf16 conv stack (bf16 operands, fp32 accumulate) on one GPU: same step
-    as the headline (forward + softmax + decode + align); reported beside it, never as `value` (the
-    reference computes in fp32).  NME: bf16 landmarks vs the fp32 HIP path on the same crops, all-pixel
-    centroid (a top-n selection amplifies bf16 noise into pixel jumps on random-weight heatmaps)."""
-    import numpy as np
+# ---- the harness (shared with tests/test_bench_harness_gloo.py, which injects a CPU step) --------------------------
+def timed_region(step, steps, warmup, world=1, device=None, settle_s=0.0, before_timed=None):
+    """W untimed warm-up steps (+ `settle_s` seconds more of them, so the clocks have settled when a short timed region
+    starts), then EXACTLY `steps` steps bracketed by barrier + device synchronise on both sides; returns the wall time in
+    seconds, MAX over ranks, and the last step's result."""
     import torch
-    from flm_amd import _lib, alignment
-    from flm_amd.networks import LANDMARKS_MODELS
-    from flm_amd.weights import synth_fcn8_weights
-    H = W = 256
-    model = LANDMARKS_MODELS["fcn_8"](68, input_height=H, input_width=W, dtype="bf16")
-    model.load_weights(synth_fcn8_weights(68, seed=2))
-    crops = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (batch, H, W, 3), dtype=np.uint8)).to(dev)
-    tmpl = torch.from_numpy(alignment.canonical_template(68, H, W)).to(dev)
-    scale = (W / model.output_width, H / model.output_height)
+    import torch.distributed as dist
+    on_gpu = device is not None and getattr(device, "type", "cpu") == "cuda"
 
-    def step():
-        lm = model.forward_device(crops, "landmarks", n_points=n_points, thresh=0.0)
-        alignment.align_device(crops, lm, tmpl, H, W, scale)
-        return lm
+    def fence():
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
 
+    out = None
     for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
+        out = step()
+    if settle_s > 0:
+        # a COUNT of extra steps agreed between the ranks (a time-based loop would run a different number of
+        # collectives on each rank): one probe step gives the step time, the slowest rank's count is taken
+        if on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = step()
+        if on_gpu:
+            torch.cuda.synchronize()
+        extra = min(500, int(settle_s / max(time.perf_counter() - t0, 1e-5)))
+        if world > 1:
+            t = torch.tensor([extra], dtype=torch.int64, device=device if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            extra = int(t.item())
+        for _ in range(extra):
+            out = step()
+    if before_timed is not None:
+        before_timed()
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
+        out = step()
+    fence()
     dt = time.perf_counter() - t0
-    # per-layer durations: a separate pass with every launch bracketed by HIP events (outside the timed region)
-    _lib.check(lib.flm_profile_enable(LAYER_PASS_STEPS * RECORDS_PER_STEP + 64), "flm_profile_enable")
-    lib.flm_profile_filter(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def describe_collective(world, device=None, payload_rows=0, classes=68, dtype_name="f64"):
+    """What a reader needs to check that the collective really ran over `world` ranks: the world size torch.distributed
+    reports after init, the backend, the RCCL version, every rank's device name."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1 or not dist.is_initialized():
+        return {"op": "none", "ranks_seen": 1, "backend": None, "rccl_version": None,
+                "devices": [torch.cuda.get_device_name(device)] if device is not None and device.type == "cuda" else ["cpu"]}
+    on_gpu = device is not None and device.type == "cuda"
+    mine = "%s (cuda:%d)" % (torch.cuda.get_device_name(device), device.index) if on_gpu else "cpu"
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, mine)
+    ver = None
+    if on_gpu:
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 -- version probe only
+            ver = "unknown"
+    es = 8 if dtype_name == "f64" else 4
+    return {"op": "all_gather_into_tensor", "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+            "rccl_version": ver, "devices": names,
+            "payload": "[%d,%d,2] %s per rank = %d B (float64 is what the reference's decode returns, utils/metrics.py:"
+                       "102-109, and keeps the gathered coordinates the single-GPU bits; latency-bound either way)"
+                       % (payload_rows, classes, dtype_name, payload_rows * classes * 2 * es)}
+
+
+class Workload:
+    """One configuration of the step on this rank: model, resident crops, template."""
+
+    def __init__(self, dtype, batch, rank, n_points, align=True, seed=1):
+        import numpy as np
+        import torch
+        from flm_amd import _lib, alignment
+        from flm_amd.networks import LANDMARKS_MODELS
+        from flm_amd.weights import synth_fcn8_weights
+        self.dtype, self.batch, self.n_points, self.align = dtype, batch, n_points, align
+        self.H = self.W = 256
+        self.dev = _lib.require_gpu()
+        self.model = LANDMARKS_MODELS["fcn_8"](68, input_height=self.H, input_width=self.W, dtype=dtype)
+        self.model.load_weights(synth_fcn8_weights(68, seed=2))
+        rng = np.random.default_rng(seed + rank)
+        self.crops = torch.from_numpy(rng.integers(0, 256, (batch, self.H, self.W, 3), dtype=np.uint8)).to(self.dev)
+        self.tmpl = torch.from_numpy(alignment.canonical_template(68, self.H, self.W)).to(self.dev)
+        self.scale = (self.W / self.model.output_width, self.H / self.model.output_height)
+
+    def make_step(self, world, total):
+        from flm_amd import alignment, distributed
+
+        def step():
+            lm = self.model.forward_device(self.crops, "landmarks", n_points=self.n_points, thresh=0.0)
+            aligned = None
+            if self.align:
+                aligned, _m = alignment.align_device(self.crops, lm, self.tmpl, self.H, self.W, self.scale)
+            full = distributed.all_gather_landmarks(lm, total) if world > 1 else lm
+            return full, aligned
+        return step
+
+
+def measure(lib, wl, steps, warmup, world, roof_layer, settle_s):
+    """Timed region of one workload with the roofline kernel's launches bracketed by HIP events on the launch stream,
+    then the per-layer pass.  Returns (seconds, roofline-layer ms, {layer: ms})."""
+    import torch
+    from flm_amd import _lib
+    step = wl.make_step(world, wl.batch * world)
+    _lib.check(lib.flm_profile_enable(max(steps, LAYER_PASS_STEPS) * RECORDS_PER_STEP + 64), "flm_profile_enable")
+    _lib.check(lib.flm_profile_filter(roof_layer.encode()), "flm_profile_filter")
+
+    dt, _ = timed_region(step, steps, warmup, world, wl.dev, settle_s, before_timed=lib.flm_profile_reset)
+    roof_ms = read_profile(lib).get(roof_layer, float("nan"))
+    _lib.check(lib.flm_profile_filter(None), "flm_profile_filter")
     lib.flm_profile_reset()
     for _ in range(LAYER_PASS_STEPS):
         step()
     torch.cuda.synchronize()
     layers = read_profile(lib)
     lib.flm_profile_disable()
+    return dt, roof_ms, layers
+
+
+def forward_summary(layers, batch, peak):
     fwd_ms = sum(v for k, v in layers.items() if k not in DECODE_KEYS)
-    nb = min(64, batch)
-    a = model.forward_device(crops[:nb].contiguous(), "landmarks", n_points=0).cpu().numpy()
-    b = fp32_model.forward_device(crops[:nb].contiguous(), "landmarks", n_points=0).cpu().numpy()
-    err = np.linalg.norm(a - b, axis=-1)
-    return {"workload": "BASELINE configs[2]: batch=%d 256x256 crops, bf16 operands / fp32 accumulate, same step "
-                        "as the headline" % batch,
-            "dtype": "bf16", "faces_per_s": batch * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "forward_ms": fwd_ms, "forward_tflops": GFLOP_PER_FACE * batch / fwd_ms,
-            "frac_of_bf16_mfma_peak": GFLOP_PER_FACE * batch / fwd_ms / PEAK_BF16_TFLOPS,
-            "layer_ms": layers,
-            "landmark_nme_vs_fp32_hip": float(err.mean() / 256.0), "max_coord_err_px": float(np.abs(a - b).max())}
+    table = {}
+    for k, ms in layers.items():
+        if k in WORK:
+            table[k] = {"ms": ms, "useful_tflops": WORK[k][1] * batch / ms, "frac": WORK[k][1] * batch / ms / peak}
+    return {"gflop_per_face_useful": USEFUL_GFLOP_PER_FACE, "gflop_per_face_dense": GFLOP_PER_FACE, "ms": fwd_ms,
+            "tflops": USEFUL_GFLOP_PER_FACE * batch / fwd_ms,
+            "frac_of_mfma_peak": USEFUL_GFLOP_PER_FACE * batch / fwd_ms / peak,
+            "tflops_dense": GFLOP_PER_FACE * batch / fwd_ms,
+            "frac_dense": GFLOP_PER_FACE * batch / fwd_ms / peak,
+            "faces_per_s_forward_only": 1e3 * batch / fwd_ms, "layer_ms": layers, "layer_roofline": table,
+            "note": "tflops / frac price USEFUL 2*MAC (no zero-padding products, %.3f GFLOP per face); *_dense use "
+                    "SURVEY 8(d)'s 17.844.  layer_ms: separate pass of %d steps after the timed region, every launch "
+                    "bracketed by HIP events" % (USEFUL_GFLOP_PER_FACE, LAYER_PASS_STEPS)}
 
 
+def mfma_roofline(layer, kernel, ms, batch, peak, traffic_file, extra=None):
+    dense, useful = WORK[layer]
+    r = {"bound": "mfma", "kernel": kernel, "achieved": useful * batch / ms, "peak": peak, "unit": "TFLOP/s",
+         "frac": useful * batch / ms / peak, "traffic": load_traffic(traffic_file, layer),
+         "flop_per_launch": useful * 1e9 * batch, "avg_launch_ms": ms,
+         "frac_dense": dense * batch / ms / peak,
+         "traffic_source": "committed profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE "
+                           "doubled per MI355X_MICROARCH.md), not measured by this run" % traffic_file,
+         "note": "achieved = useful 2*MAC per launch (products with zero padding excluded) / mean launch duration from "
+                 "HIP events on the launch stream inside the timed region; frac_dense uses SURVEY 8(d)'s dense count"}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def hbm_kernels(lib, dev):
+    """The HBM-bound kernels on their own (outside any timed region): standalone decode of materialised heatmaps and the
+    alignment warp, algorithmic bytes / mean launch duration / 8 TB/s."""
+    import torch
+    from flm_amd import alignment
+    from flm_amd.utils.metrics import decode_device
+    out = {}
+
+    def timeit(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for nb in (64, 512):
+        hm = torch.rand((nb, 264, 264, 68), dtype=torch.float32, device=dev)
+        ms = timeit(lambda: decode_device(hm, 4, 0.0))
+        gbs = DECODE_BYTES_PER_FACE * nb / ms / 1e6
+        out["decode_top4_b%d" % nb] = {"bound": "hbm", "kernel": "decode_partial_kernel + decode_merge_kernel (flm_decode, "
+                                       "float32 [%d,264,264,68] -> landmarks)" % nb, "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": ms,
+                                       "bytes_per_launch": DECODE_BYTES_PER_FACE * nb,
+                                       "traffic": load_traffic("traffic_latest.json", "decode_standalone_b%d" % nb)}
+        del hm
+    for nb in (64, 512):
+        src = torch.randint(0, 256, (nb, 256, 256, 3), dtype=torch.uint8, device=dev)
+        m = torch.tensor([[0.98, 0.05, 2.0], [-0.05, 0.98, 3.0]], dtype=torch.float32, device=dev).repeat(nb, 1, 1).contiguous()
+        dst = torch.empty((nb, 256, 256, 3), dtype=torch.float32, device=dev)
+        ms = timeit(lambda: alignment.warp_device(src, m, 256, 256, out=dst))
+        gbs = WARP_BYTES_PER_FACE * nb / ms / 1e6
+        out["warp_b%d" % nb] = {"bound": "hbm", "kernel": "warp_kernel (flm_warp_affine, u8 [%d,256,256,3] -> f32)" % nb,
+                                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                "avg_launch_ms": ms, "bytes_per_launch": WARP_BYTES_PER_FACE * nb,
+                                "traffic": load_traffic("traffic_latest.json", "warp_b%d" % nb)}
+        del src, dst
+    return out
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------------------------
 def usable_cores():
     """CPUs this process may really use: the affinity mask, cut by a cgroup CPU quota if one is set (the GPU box hands a
     16-CPU share of a 256-thread host: os.cpu_count() alone oversubscribes the baseline 16x)."""
@@ -166,9 +355,10 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(n_faces, n_points, seed):
-    """The oracle (kind "port": the build's CPU restatement of prediction.py's path) timed on the
-    host cores: preprocess + FCN-8 forward + softmax + top-n decode for `n_faces` crops."""
+def cpu_baseline(n_faces, n_points, seed, reps=5, warmups=2):
+    """The oracle (kind "port": the build's CPU restatement of prediction.py's path) timed on the host cores: preprocess +
+    FCN-8 forward + softmax + top-n decode of `n_faces` crops per repetition; BASELINE.md section 3's protocol (2 warm-ups,
+    median of >= 5 repetitions) on a sample bounded to ~15 s of CPU work (the first `n_faces` crops of the headline batch)."""
     import numpy as np
     import torch
     from flm_amd.weights import synth_fcn8_weights
@@ -177,7 +367,7 @@ def cpu_baseline(n_faces, n_points, seed):
     torch.set_num_threads(cores)
     params = synth_fcn8_weights(68, seed=2)
     rng = np.random.default_rng(seed)
-    crops = rng.integers(0, 256, (n_faces, 256, 256, 3), dtype=np.uint8)
+    crops = rng.integers(0, 256, (64, 256, 256, 3), dtype=np.uint8)[:n_faces]
 
     def decode_face(hm_one):  # the reference's per-landmark argsort loop (utils/metrics.py:66-77), one face
         with np.errstate(all="ignore"):
@@ -190,40 +380,73 @@ def cpu_baseline(n_faces, n_points, seed):
         with concurrent.futures.ThreadPoolExecutor(max_workers=cores) as ex:
             return np.concatenate(list(ex.map(decode_face, [pr[i:i + 1] for i in range(len(c))])))
 
-    run(crops[:1])  # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    lm = run(crops)
-    dt = time.perf_counter() - t0
-    return {"value": n_faces / dt, "unit": "faces/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic 256x256 crops through oracle/ (torch-CPU fp32 forward on %d threads + numpy "
-                      "top-%d decode, one face per thread), %.1f s" % (n_faces, cores, n_points, dt)}, lm, crops
+    for _ in range(warmups):
+        run(crops)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        lm = run(crops)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": n_faces / med, "unit": "faces/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic 256x256 crops per repetition through oracle/ (torch-CPU fp32 forward on %d threads + "
+                      "numpy top-%d decode, one face per thread); %d warm-ups, median of %d repetitions (%.2f s each, "
+                      "min %.2f max %.2f)" % (n_faces, cores, n_points, warmups, reps, med, min(times), max(times))}, lm, crops
+
+
+# ---- main ----------------------------------------------------------------------------------------------------------
+def bf16_side_object(lib, args, world, rank, tag):
+    """BASELINE configs[2] (N = 1) / configs[3] (N > 1): 512 bf16 faces per rank, same step, own timed region."""
+    wl = Workload("bf16", args.bf16_batch, rank, args.n_points, not args.no_align, seed=3)
+    steps = max(5, args.steps)
+    dt, up3_ms, layers = measure(lib, wl, steps, max(2, args.warmup), world, "up3", args.settle_ms / 1e3)
+    total = wl.batch * world
+    fwd = forward_summary(layers, wl.batch, PEAK_BF16_TFLOPS)
+    obj = {"workload": "%s: %d faces per GPU x %d GPU(s), 256x256 crops, bf16 operands / fp32 accumulate, same step as "
+                       "the headline%s" % (tag, wl.batch, world, " + all-gather of the landmarks" if world > 1 else ""),
+           "dtype": "bf16", "n_gpus": world, "faces_per_s": total * steps / dt, "ms_per_step": 1e3 * dt / steps,
+           "steps": steps,
+           "roofline": mfma_roofline("up3", "convt_kernel<5,9,bf16,...> (up3: Conv2DTranspose 16x16 s8 68->68 on 32x32, "
+                                     "softmax + candidate keys in the epilogue)", up3_ms, wl.batch, PEAK_BF16_TFLOPS,
+                                     "traffic_bf16_latest.json"),
+           "forward": fwd}
+    return obj, wl
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="faces per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="BASELINE.json configs[config-1] as the headline: 2 = 64 fp32 faces per GPU (default), 3 = 512 "
+                         "bf16 faces on one GPU, 4 = 512 bf16 faces per GPU + all-gather")
+    ap.add_argument("--batch", type=int, default=0, help="faces per GPU per step (0 = the configuration's: 64 or 512)")
     ap.add_argument("--n-points", type=int, default=4)
-    ap.add_argument("--cpu-faces", type=int, default=64, help="sample size of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-faces", type=int, default=16, help="faces per repetition of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-align", action="store_true")
     ap.add_argument("--bf16-batch", type=int, default=512,
-                    help="also time BASELINE configs[2] (bf16 operands, this many faces per step) on rank 0 "
-                         "and report it as a side object; 0 = skip")
+                    help="with --config 2: also time the bf16 configuration (this many faces per GPU per step) and report "
+                         "it as a side object (`bf16_config3` at N = 1, `config4` at N > 1); 0 = skip")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="extra untimed warm-up before the timed region so a short region starts at settled clocks")
+    ap.add_argument("--no-hbm-kernels", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import flm_amd  # noqa: F401
-    from flm_amd import _lib, alignment, distributed
-    from flm_amd.networks import LANDMARKS_MODELS
-    from flm_amd.weights import synth_fcn8_weights
+    from flm_amd import _lib, distributed
 
     rank, local_rank, world = distributed.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                         "--nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+    if args.config == 3 and world > 1:
+        raise SystemExit("--config 3 is the one-GPU bf16 run; use --config 4 for N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank if world > 1 else 0)
@@ -232,112 +455,78 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.load()
 
-    B, H, W, CLS = args.batch, 256, 256, 68
-    model = LANDMARKS_MODELS["fcn_8"](CLS, input_height=H, input_width=W)
-    model.load_weights(synth_fcn8_weights(CLS, seed=2))
-    rng = np.random.default_rng(1 + rank)
-    crops = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(dev)
-    tmpl = torch.from_numpy(alignment.canonical_template(CLS, H, W)).to(dev)
-    scale = (model.input_width / model.output_width, model.input_height / model.output_height)
+    bf16_head = args.config in (3, 4)
+    dtype = "bf16" if bf16_head else "f32"
+    B = args.batch or (512 if bf16_head else 64)
+    CLS = 68
+    wl = Workload(dtype, B, rank, args.n_points, not args.no_align, seed=3 if bf16_head else 1)
+    roof_layer = "up3" if bf16_head else "fc6"
+    peak = PEAK_BF16_TFLOPS if bf16_head else PEAK_F32_TFLOPS
+    dt, roof_ms, layer_avg = measure(lib, wl, args.steps, args.warmup, world, roof_layer, args.settle_ms / 1e3)
     total = B * world
+    coll = describe_collective(world, dev, B, CLS)
 
-    def step():
-        lm = model.forward_device(crops, "landmarks", n_points=args.n_points, thresh=0.0)
-        if not args.no_align:
-            aligned, m = alignment.align_device(crops, lm, tmpl, H, W, scale)
-        else:
-            aligned = None
-        full = distributed.all_gather_landmarks(lm, total) if world > 1 else lm
-        return full, aligned
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    # Timed region: only the roofline kernel (fc6) is bracketed by HIP events on the launch stream -- an event pair
-    # around each of the ~18 launches of a step costs 1.7 % of the step.  The per-layer table comes from a separate
-    # pass right after it.
-    _lib.check(lib.flm_profile_enable(max(args.steps, LAYER_PASS_STEPS) * RECORDS_PER_STEP + 64), "flm_profile_enable")
-    _lib.check(lib.flm_profile_filter(b"fc6"), "flm_profile_filter")
-    lib.flm_profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full, aligned = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- fc6 launch durations recorded by HIP events inside the timed region; then the per-layer pass ----
-    fc6_timed = read_profile(lib).get("fc6", float("nan"))
-    _lib.check(lib.flm_profile_filter(None), "flm_profile_filter")
-    lib.flm_profile_reset()
-    for _ in range(LAYER_PASS_STEPS):
-        step()
-    fence()
-    layer_avg = read_profile(lib)
-    lib.flm_profile_disable()
+    side = None
+    side_coll = describe_collective(world, dev, args.bf16_batch, CLS) if world > 1 else None
+    if args.config == 2 and args.bf16_batch > 0:
+        side, wl16 = bf16_side_object(lib, args, world, rank,
+                                      "BASELINE configs[2]" if world == 1 else "BASELINE configs[3]")
+        if world == 1 and rank == 0:   # bf16 landmarks of the whole 512 batch against the fp32 HIP path, same crops
+            a = wl16.model.forward_device(wl16.crops, "landmarks", n_points=0).cpu().numpy()
+            b = wl.model.forward_device(wl16.crops, "landmarks", n_points=0).cpu().numpy()
+            err = np.linalg.norm(a - b, axis=-1)
+            side["landmark_nme_vs_fp32_hip"] = float(err.mean() / 256.0)
+            side["max_coord_err_px"] = float(np.abs(a - b).max())
+            side["parity_note"] = "all-pixel centroid, all %d faces of the timed batch (tests/test_gpu_baseline_configs.py " \
+                                  "gates the same at batch 512 and checks the candidate path bit for bit)" % wl16.batch
+        del wl16
 
     if rank == 0:
         value = total * args.steps / dt
-        fwd_keys = [k for k in layer_avg if k not in DECODE_KEYS]
-        fwd_ms = sum(layer_avg[k] for k in fwd_keys)
-        fc6_ms = fc6_timed
-        fc6_tflops = FC6_GFLOP_PER_FACE * B / fc6_ms  # GFLOP / ms = TFLOP/s
-        fwd_tflops = GFLOP_PER_FACE * B / fwd_ms
+        names = {2: "BASELINE configs[1]", 3: "BASELINE configs[2]", 4: "BASELINE configs[3]"}
+        if bf16_head:
+            roof = mfma_roofline("up3", "convt_kernel<5,9,bf16,...> (up3 + softmax + candidate keys)", roof_ms, B, peak,
+                                 "traffic_bf16_latest.json")
+        else:
+            issued = fc6_issued_gflop(B)
+            roof = mfma_roofline("fc6", "igemm_kernel<f32,MMAP=2,RELU> (fc6: 7x7x256->4096 on 8x8, M=64*B, K=12544)",
+                                 roof_ms, B, peak, "traffic_latest.json",
+                                 {"issued_tflops": issued / roof_ms, "frac_issued": issued / roof_ms / peak})
         rec = {
             "metric": "faces/sec (whole node), 256x256 batch inference: fused preprocess + FCN-8 forward + "
                       "softmax + top-%d landmark decode + similarity/alignment warp" % args.n_points,
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=%d/GPU 256x256x3 uint8 crops, fcn_8(68) vanilla "
-                                   "encoder fp32, random-init weights (seed 2), decode top-%d thresh 0, "
-                                   "align to 256x256%s" % (B, args.n_points, "" if not args.no_align else " (off)"),
-                       "faces_per_gpu_per_step": B, "parallelism": "dp%d" % world,
-                       "collective": "all_gather landmarks [B,68,2] f64" if world > 1 else "none"},
-            "roofline": {"bound": "mfma",
-                         "kernel": "igemm_f32_kernel<MMAP=2,RELU> (fc6: 7x7x256->4096 on 8x8, M=64*B, K=12544)",
-                         "achieved": fc6_tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fc6_tflops / PEAK_F32_TFLOPS, "traffic": load_traffic("fc6"),
-                         "flop_per_launch": FC6_GFLOP_PER_FACE * 1e9 * B, "avg_launch_ms": fc6_ms,
-                         "issued_tflops": fc6_issued_gflop(B) / fc6_ms,
-                         "frac_issued": fc6_issued_gflop(B) / fc6_ms / PEAK_F32_TFLOPS,
-                         "note": "achieved counts the dense 2*MAC of SURVEY 8(d) (zero-padded taps included); the "
-                                 "kernel skips taps that only see padding, so fewer MFMAs are issued: "
-                                 "issued_tflops / frac_issued price the matrix pipe itself",
-                         "traffic_source": "profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"},
-            "forward": {"gflop_per_face": GFLOP_PER_FACE, "ms": fwd_ms, "tflops": fwd_tflops,
-                        "frac_of_f32_mfma_peak": fwd_tflops / PEAK_F32_TFLOPS,
-                        "faces_per_s_forward_only": 1e3 * B / fwd_ms, "layer_ms": layer_avg,
-                        "layer_ms_source": "separate pass of %d steps right after the timed region, every launch "
-                                           "bracketed by HIP events (the timed region brackets fc6 only)"
-                                           % LAYER_PASS_STEPS},
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "%s: batch=%d/GPU 256x256x3 uint8 crops, fcn_8(68) vanilla encoder %s, random-init "
+                                   "weights (seed 2), decode top-%d thresh 0, align to 256x256%s"
+                                   % (names[args.config], B, "fp32" if not bf16_head else "bf16 operands / fp32 accumulate",
+                                      args.n_points, "" if not args.no_align else " (off)"),
+                       "faces_per_gpu_per_step": B, "global_batch": total, "parallelism": "dp%d" % world,
+                       "collective": coll, "settle_ms_before_timed_region": args.settle_ms},
+            "roofline": roof,
+            "forward": forward_summary(layer_avg, B, peak),
         }
-        if args.cpu_faces > 0 and world == 1:   # CPU leg: rank 0 at N=1 only
+        if args.cpu_faces > 0 and world == 1 and not bf16_head:   # CPU leg: rank 0 at N=1 only
             base, lm_cpu, crops_cpu = cpu_baseline(args.cpu_faces, args.n_points, seed=1)
             rec["cpu_baseline"] = base
             # the same crops on the GPU: landmark NME vs the oracle (NME := mean ||p - p_ref|| / 256)
-            nb = min(args.cpu_faces, B)
-            xd = torch.from_numpy(crops_cpu[:nb]).to(dev)
-            got = model.forward_device(xd, "landmarks", n_points=args.n_points).cpu().numpy()
-            ref = lm_cpu[:nb].reshape(nb, CLS, 2)
+            nb = len(crops_cpu)
+            xd = torch.from_numpy(crops_cpu).to(dev)
+            got = wl.model.forward_device(xd, "landmarks", n_points=args.n_points).cpu().numpy()
+            ref = lm_cpu.reshape(nb, CLS, 2)
             err = np.linalg.norm(got - ref, axis=-1)
             rec["parity"] = {"landmark_nme_vs_oracle": float(err.mean() / 256.0),
                              "max_coord_err_px": float(np.abs(got - ref).max()), "faces": nb,
-                             "note": "against the float32 oracle; a top-4 centroid divides by the sum of four ~1e-2 "
-                                     "probabilities, so two float32 forwards with different summation orders differ "
-                                     "by up to ~1e-4 px there -- tests/test_gpu_forward.py gates both against the "
-                                     "oracle's float64 evaluation"}
-        if args.bf16_batch > 0 and world == 1:
-            rec["bf16_config3"] = bf16_config3(lib, dev, args.bf16_batch, max(3, args.steps // 2), 2, args.n_points,
-                                               model)
+                             "note": "against the float32 oracle on the CPU leg's crops (two float32 evaluations of the "
+                                     "network); the gate against the float64 oracle on all 64 faces of configs[1] is "
+                                     "tests/test_gpu_baseline_configs.py"}
+        if not args.no_hbm_kernels and world == 1:
+            rec["hbm_kernels"] = hbm_kernels(lib, dev)
+        if side is not None:
+            if world > 1:
+                side["collective"] = side_coll
+            rec["bf16_config3" if world == 1 else "config4"] = side
         print(json.dumps(rec))
     if world > 1:
         dist.barrier()
