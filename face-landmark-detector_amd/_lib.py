@@ -16,13 +16,14 @@ IN_U8_BGR, IN_F32_RGB = 0, 1
 OUT_PROBS, OUT_CLASSMAP, OUT_LANDMARKS, OUT_LOGITS = 0, 1, 2, 3
 DECODE_ALL, DECODE_TOPN = 0, 1
 NORM_SUB_MEAN, NORM_SUB_AND_DIVIDE, NORM_DIVIDE = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "flm_abi_version", "flm_last_error",
     "flm_fcn8_packed_bytes", "flm_fcn8_pack",
     "flm_fcn32_packed_bytes", "flm_fcn32_pack", "flm_fcn32_workspace_bytes", "flm_fcn32_forward",
     "flm_fcn_packed_bytes", "flm_fcn_pack", "flm_fcn_workspace_bytes", "flm_fcn_forward",
+    "flm_forward_opts_init", "flm_fcn_workspace_bytes_opts", "flm_fcn_forward_opts", "flm_fcn8_workspace_offset_opts",
     "flm_fcn8_workspace_bytes", "flm_fcn8_forward", "flm_fcn8_workspace_offset", "flm_fcn8_run_layer",
     "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_filter", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
@@ -43,6 +44,24 @@ class Fcn8Params(C.Structure):
     _fields_ = [("enc", ConvParams * 5), ("fc6", ConvParams), ("fc7", ConvParams),
                 ("score5", ConvParams), ("score4", ConvParams), ("score3", ConvParams),
                 ("up5", C.c_void_p), ("up4", C.c_void_p), ("up3", C.c_void_p)]
+
+
+class ForwardOpts(C.Structure):
+    """flm_forward_opts: per-call options that change the workspace layout (include/flm.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("landmark_candidates", C.c_int32), ("candidate_sub_phases", C.c_int32),
+                ("candidate_cap_div", C.c_int32)]
+
+    @classmethod
+    def make(cls, landmark_candidates=1, candidate_sub_phases=0, candidate_cap_div=1):
+        o = cls()
+        load().flm_forward_opts_init(C.byref(o))
+        o.landmark_candidates = int(landmark_candidates)
+        o.candidate_sub_phases = int(candidate_sub_phases)
+        o.candidate_cap_div = int(candidate_cap_div)
+        return o
+
+    def key(self):
+        return (self.landmark_candidates, self.candidate_sub_phases, self.candidate_cap_div)
 
 
 class FcnParams(C.Structure):
@@ -87,6 +106,14 @@ def _declare(lib):
     lib.flm_fcn_workspace_bytes.argtypes = [i] * 9
     lib.flm_fcn_forward.restype = i
     lib.flm_fcn_forward.argtypes = [vp, i, vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp, sz]
+    lib.flm_forward_opts_init.restype = None
+    lib.flm_forward_opts_init.argtypes = [C.POINTER(ForwardOpts)]
+    lib.flm_fcn_workspace_bytes_opts.restype = sz
+    lib.flm_fcn_workspace_bytes_opts.argtypes = [i] * 9 + [C.POINTER(ForwardOpts)]
+    lib.flm_fcn_forward_opts.restype = i
+    lib.flm_fcn_forward_opts.argtypes = [vp, i, vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp, sz, C.POINTER(ForwardOpts)]
+    lib.flm_fcn8_workspace_offset_opts.restype = C.c_int64
+    lib.flm_fcn8_workspace_offset_opts.argtypes = [C.c_char_p] + [i] * 8 + [C.POINTER(ForwardOpts)]
     lib.flm_fcn8_workspace_offset.restype = C.c_int64
     lib.flm_fcn8_workspace_offset.argtypes = [C.c_char_p] + [i] * 8
     lib.flm_fcn8_run_layer.restype = i

@@ -52,20 +52,49 @@ struct ProfScope {
 // below 2^17 pixels.  On by default for both types: bf16 batch
 // 512 saves the tensor's write + re-read (up3 + decode 6.2 -> 3.5 ms); fp32 batch 64 gains 1.5 % of the step (the
 // fp32 up3 is bound by the matrix pipe and writes its map for free; the gain is the decode).  0 = off (tests, A/B).
-static int g_cand_enable = 1;
-static int g_cand_cap_div = 1;  // > 1 shrinks the per-face list (tests force the overflow fallback with it)
-static int g_cand_sub = 0;      // phases per tile in the sampling launch (R of flm_convt.hip); 0: by n_points
+// These three are per-call options (flm_forward_opts): they change the workspace layout, so they travel with the call
+// and with its workspace query instead of living in process state.
+struct CandOpts {
+  int enable, sub, cap_div;
+};
+static bool resolve_opts(const flm_forward_opts* o, CandOpts* c) {
+  c->enable = 1;
+  c->sub = 0;
+  c->cap_div = 1;
+  if (!o) return true;
+  if (o->struct_size < sizeof(flm_forward_opts)) {
+    set_error("flm_forward_opts: struct_size %u is smaller than this library's %zu (initialise with flm_forward_opts_init)",
+              o->struct_size, sizeof(flm_forward_opts));
+    return false;
+  }
+  if (o->candidate_sub_phases < 0 || o->candidate_sub_phases > 16 || o->candidate_cap_div < 1) {
+    set_error("flm_forward_opts: candidate_sub_phases must be in [0,16] and candidate_cap_div >= 1");
+    return false;
+  }
+  c->enable = o->landmark_candidates != 0;
+  c->sub = o->candidate_sub_phases;
+  c->cap_div = o->candidate_cap_div;
+  return true;
+}
 // More sampled phases cost 1/64 of up3 each and tighten the threshold: the key lists shrink about in proportion.  At
 // n = 4 the lists are short anyway (4 phases: 8-10 k keys per face); at n >= 16 their merge costs more than the extra
 // phases (batch 512 bf16, n = 25: 12.1 ms with 4 phases, 11.5 with 8; tools/ab_sub.py).
-static int cand_sub_for(int n_points) {
-  if (g_cand_sub > 0) return g_cand_sub;
+static int cand_sub_for(const CandOpts& c, int n_points) {
+  if (c.sub > 0) return c.sub;
   return n_points <= 8 ? 4 : (n_points <= 15 ? 6 : 8);
 }
-static bool landmark_candidates_enabled(const ConvTGeom& g, int fcn32, int decode_mode, int n_points, int oh, int ow) {
-  return g_cand_enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 32 &&
+static bool landmark_candidates_enabled(const CandOpts& c, const ConvTGeom& g, int fcn32, int decode_mode, int n_points,
+                                        int oh, int ow) {
+  return c.enable && !fcn32 && decode_mode == FLM_DECODE_TOPN && n_points >= 1 && n_points <= 32 &&
          convt_candidates_supported(g) && (long long)oh * ow < (1 << 17);
 }
+
+struct EncNames {
+  char s[kMaxEnc][8];
+  EncNames() {
+    for (int i = 0; i < kMaxEnc; ++i) snprintf(s[i], sizeof(s[i]), "enc%d", i + 1);
+  }
+};
 
 static size_t take(size_t& cur, size_t bytes) {
   size_t o = cur;
@@ -74,8 +103,14 @@ static size_t take(size_t& cur, size_t bytes) {
 }
 
 Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points,
-                      int arch) {
+                      int arch, const flm_forward_opts* opts) {
   Fcn8Ws W;
+  CandOpts co;
+  if (!resolve_opts(opts, &co)) {  // callers validate first (check_opts); an invalid struct sizes nothing
+    W = Fcn8Ws();
+    W.total = 0;
+    return W;
+  }
   const ConvTGeom g = convt_geom(C, dtype);
   const ArchSpec A = arch_spec(arch);
   const size_t es = dtype == FLM_BF16 ? 2 : 4;  // encoder activations, fc6, fc7 are stored in the operand type
@@ -112,12 +147,12 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
   if (out_mode == FLM_OUT_LANDMARKS) {
     W.probs = take(cur, sizeof(float) * (size_t)n * W.oh * W.ow * C);
     W.decode = take(cur, decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
-    if (landmark_candidates_enabled(g, A.fcn32, decode_mode, n_points, W.oh, W.ow)) {
+    if (landmark_candidates_enabled(co, g, A.fcn32, decode_mode, n_points, W.oh, W.ow)) {
       const int h3 = h / 8, w3 = w / 8;
-      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, cand_sub_for(n_points)) * 16 * g.MT);  // sampled maxima
+      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, cand_sub_for(co, n_points)) * 16 * g.MT);  // sampled maxima
       W.tau = take(cur, sizeof(float) * (size_t)n * C);
       // expected keys per class: the n-th of 1/64 of the pixels ranks about 64*n-th overall; x4 head room
-      W.cand_cap = (int)align_up((size_t)C * 64 * n_points * 4 / g_cand_cap_div, 64);
+      W.cand_cap = (int)align_up((size_t)C * 64 * n_points * 4 / co.cap_div, 64);
       W.cand = take(cur, sizeof(unsigned long long) * (size_t)n * W.cand_cap);
       W.cand_cnt = take(cur, sizeof(unsigned) * ((size_t)n + 1));
     }
@@ -193,25 +228,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::igemm_bf16_big_dma(value);
     return FLM_OK;
   }
-  if (!strcmp(key, "landmark_candidates")) {  // 0: always materialise the probabilities and decode them
-    g_cand_enable = value != 0;
-    return FLM_OK;
-  }
-  if (!strcmp(key, "candidate_sub_phases")) {
-    if (value < 0 || value > 16) {
-      set_error("flm_set_tuning: candidate_sub_phases must be in [0,16]");
-      return FLM_ERR_ARG;
-    }
-    g_cand_sub = value;
-    return FLM_OK;
-  }
-  if (!strcmp(key, "candidate_cap_div")) {  // shrink the candidate lists (tests of the overflow fallback)
-    if (value < 1) {
-      set_error("flm_set_tuning: candidate_cap_div must be >= 1");
-      return FLM_ERR_ARG;
-    }
-    g_cand_cap_div = value;
-    return FLM_OK;
+  if (!strcmp(key, "landmark_candidates") || !strcmp(key, "candidate_sub_phases") || !strcmp(key, "candidate_cap_div")) {
+    set_error("flm_set_tuning: '%s' changes the workspace layout and is a per-call option now: pass flm_forward_opts to "
+              "flm_fcn_workspace_bytes_opts / flm_fcn_forward_opts", key);
+    return FLM_ERR_ARG;
   }
   if (!strcmp(key, "bf16_conv3_halo")) {  // halo-resident 3x3 kernel for 64-channel inputs: 0 off, 1 auto, 2 always
     flm::conv3_halo_enable(value);
@@ -358,16 +378,32 @@ size_t flm_fcn32_workspace_bytes(int n, int h, int w, int n_classes, int dtype, 
   if (check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
   return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, FLM_ARCH_FCN32).total;
 }
+size_t flm_fcn_workspace_bytes_opts(int arch, int n, int h, int w, int n_classes, int dtype, int out_mode,
+                                    int decode_mode, int n_points, const flm_forward_opts* opts) {
+  if (!arch_spec(arch).valid || check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
+  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, arch, opts).total;
+}
 size_t flm_fcn_workspace_bytes(int arch, int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
                                int n_points) {
-  if (!arch_spec(arch).valid || check_fcn8_shape(n, h, w, n_classes, dtype)) return 0;
-  return fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, arch).total;
+  return flm_fcn_workspace_bytes_opts(arch, n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, nullptr);
+}
+void flm_forward_opts_init(flm_forward_opts* opts) {
+  if (!opts) return;
+  opts->struct_size = (uint32_t)sizeof(flm_forward_opts);
+  opts->landmark_candidates = 1;
+  opts->candidate_sub_phases = 0;
+  opts->candidate_cap_div = 1;
 }
 
 int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_classes, int dtype, int out_mode,
                                   int decode_mode, int n_points) {
+  return flm_fcn8_workspace_offset_opts(name, n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, nullptr);
+}
+int64_t flm_fcn8_workspace_offset_opts(const char* name, int n, int h, int w, int n_classes, int dtype, int out_mode,
+                                       int decode_mode, int n_points, const flm_forward_opts* opts) {
   if (!name || check_fcn8_shape(n, h, w, n_classes, dtype)) return -1;
-  const Fcn8Ws W = fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points);
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, n_classes, dtype, out_mode, decode_mode, n_points, FLM_ARCH_FCN8, opts);
+  if (W.total == 0) return -1;
   if (name[0] == 'f' && name[1] >= '1' && name[1] <= '5' && name[2] == 0) return (int64_t)W.f[name[1] - '1'];
   if (!strcmp(name, "cand_sub")) return W.sub == SIZE_MAX ? -1 : (int64_t)W.sub;
   if (!strcmp(name, "cand_tau")) return W.tau == SIZE_MAX ? -1 : (int64_t)W.tau;
@@ -385,8 +421,11 @@ int64_t flm_fcn8_workspace_offset(const char* name, int n, int h, int w, int n_c
 
 static int forward_impl(flm_stream_t stream, const void* packed_dev, const void* x_dev, int in_format, int n, int h,
                         int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
-                        void* out_dev, void* workspace_dev, size_t workspace_bytes, int arch) {
+                        void* out_dev, void* workspace_dev, size_t workspace_bytes, int arch,
+                        const flm_forward_opts* opts = nullptr) {
   const ArchSpec A = arch_spec(arch);
+  CandOpts co;
+  if (!resolve_opts(opts, &co)) return FLM_ERR_ARG;
   if (!A.valid) {
     set_error("flm_fcn_forward: unknown architecture %d", arch);
     return FLM_ERR_ARG;
@@ -402,7 +441,7 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     set_error("flm_fcn8_forward: unknown output mode %d", out_mode);
     return FLM_ERR_ARG;
   }
-  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points, arch);
+  const Fcn8Ws W = fcn8_ws_layout(n, h, w, C, dtype, out_mode, decode_mode, n_points, arch, opts);
   if (workspace_bytes < W.total) {
     set_error("flm_fcn8_forward: workspace too small (%zu < %zu)", workspace_bytes, W.total);
     return FLM_ERR_WORKSPACE;
@@ -421,12 +460,8 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   float* seg = reinterpret_cast<float*>(ws + W.seg);
 
   // encoder: vanilla (networks/fcn.py:10-51) or VGG16 (networks/vgg16.py:27-72)
-  static char enc_names[kMaxEnc][8];
-  static bool names_done = false;
-  if (!names_done) {
-    for (int i = 0; i < kMaxEnc; ++i) snprintf(enc_names[i], sizeof(enc_names[i]), "enc%d", i + 1);
-    names_done = true;
-  }
+  static const EncNames enc_name_table;  // "enc1".."enc64" (profile record labels); built once, thread-safe (C++11 statics)
+  const char (*enc_names)[8] = enc_name_table.s;
   int hs[kMaxEnc], wsz[kMaxEnc];
   enc_dims(A, h, w, hs, wsz);
   {
@@ -567,12 +602,12 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + W.cand);
     FLM_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned) * ((size_t)n + 1), s));
     ConvTDesc ts = t;
-    ts.y = sub; ts.epilogue = 4; ts.sub = cand_sub_for(n_points);
+    ts.y = sub; ts.epilogue = 4; ts.sub = cand_sub_for(co, n_points);
     { ProfScope ps(s, "up3_sub");
     rc = launch_convt(s, ts); }
     if (rc) return rc;
     { ProfScope ps(s, "tau");
-    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, cand_sub_for(n_points)), 16 * L.g.MT, C,
+    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, cand_sub_for(co, n_points)), 16 * L.g.MT, C,
                          n_points, tau); }
     if (rc) return rc;
     ConvTDesc tc = t;
@@ -626,6 +661,12 @@ int flm_fcn8_forward(flm_stream_t stream, const void* packed_dev, const void* x_
                      void* out_dev, void* workspace_dev, size_t workspace_bytes) {
   return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
                       out_dev, workspace_dev, workspace_bytes, FLM_ARCH_FCN8);
+}
+int flm_fcn_forward_opts(flm_stream_t stream, int arch, const void* packed_dev, const void* x_dev, int in_format, int n,
+                         int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,
+                         void* out_dev, void* workspace_dev, size_t workspace_bytes, const flm_forward_opts* opts) {
+  return forward_impl(stream, packed_dev, x_dev, in_format, n, h, w, C, dtype, out_mode, decode_mode, n_points, thresh,
+                      out_dev, workspace_dev, workspace_bytes, arch, opts);
 }
 int flm_fcn_forward(flm_stream_t stream, int arch, const void* packed_dev, const void* x_dev, int in_format, int n,
                     int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points, float thresh,

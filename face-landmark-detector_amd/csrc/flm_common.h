@@ -5,6 +5,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "flm.h"
 
 namespace flm {
@@ -22,6 +25,27 @@ int hip_fail(hipError_t e, const char* what);
   do {                                                           \
     hipError_t e_ = hipGetLastError();                           \
     if (e_ != hipSuccess) return ::flm::hip_fail(e_, what);      \
+  } while (0)
+
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) once per kernel instantiation AND device, safe under concurrent
+// callers: a launcher keeps one static FuncAttrOnce and calls FLM_FUNC_ATTR_ONCE(flag, kernel, lds) before launching.
+struct FuncAttrOnce {
+  std::atomic<unsigned> done{0};  // one bit per device ordinal
+  std::mutex mu;
+};
+#define FLM_FUNC_ATTR_ONCE(flag, kernel, lds_bytes)                                                        \
+  do {                                                                                                     \
+    int dev_ = 0;                                                                                          \
+    FLM_HIP(hipGetDevice(&dev_));                                                                          \
+    const unsigned bit_ = 1u << (dev_ & 31);                                                               \
+    if (!((flag).done.load(std::memory_order_acquire) & bit_)) {                                           \
+      std::lock_guard<std::mutex> lock_((flag).mu);                                                        \
+      if (!((flag).done.load(std::memory_order_relaxed) & bit_)) {                                         \
+        FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes)));        \
+        (flag).done.fetch_or(bit_, std::memory_order_release);                                             \
+      }                                                                                                    \
+    }                                                                                                      \
   } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -115,8 +139,9 @@ struct Fcn8Ws {
   size_t total;
   int oh, ow;
 };
+// `opts` (NULL = defaults) carries the per-call options that change the layout (include/flm.h: flm_forward_opts).
 Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int decode_mode, int n_points,
-                      int arch = 0);
+                      int arch = 0, const flm_forward_opts* opts = nullptr);
 
 // ---- kernel launchers (each returns FLM_OK or an error) --------------------------------------
 int launch_pack_fcn(hipStream_t s, const flm_fcn_params& p, int C, const Fcn8Pack& L, char* blob);

@@ -209,18 +209,14 @@ __global__ __launch_bounds__(256, 1) void conv3_halo_bf16_kernel(IgemmArgs a, in
 #undef FLM_FINAL_EPI
 }
 
-static int g_halo_enable = 1;
-void conv3_halo_enable(int on) { g_halo_enable = on; }
+static std::atomic<int> g_halo_enable{1};  // A/B knob: never changes results or layouts
+void conv3_halo_enable(int on) { g_halo_enable.store(on, std::memory_order_relaxed); }
 
 template <bool POOL, bool RELU>
 static int launch_halo_t(hipStream_t s, const IgemmArgs& a, int slices) {
   constexpr size_t lds = WSLICE_BYTES + 2 * HALO_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_bf16_kernel<POOL, RELU>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static FuncAttrOnce attr;
+  FLM_FUNC_ATTR_ONCE(attr, (&conv3_halo_bf16_kernel<POOL, RELU>), lds);
   const int tiles = a.n * (a.h / HT) * (a.w / HT);
   int wg_per_slice = 256 / slices;  // one workgroup per CU
   if (wg_per_slice > tiles) wg_per_slice = tiles;

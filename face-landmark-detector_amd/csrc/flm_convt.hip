@@ -604,12 +604,8 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
   // two workgroups per CU (160 KiB of LDS) is what the 68-class kernels are scheduled for: a key buffer that pushed the
   // fp32 candidate kernel to 94 KiB cost 22 % of up3
   static_assert(!(MT == 5 && (G == 9 || G == 17)) || MODE == 2 || lds <= 80 * 1024, "convt: LDS budget of two workgroups per CU");
-  static bool attr_done = false;
-  if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_kernel<MT, G, BF, NT, MODE, SHARE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static FuncAttrOnce attr;
+  FLM_FUNC_ATTR_ONCE(attr, (&convt_kernel<MT, G, BF, NT, MODE, SHARE>), lds);
   int xblocks = cdiv(a.P, 64 * NT);
   if (a.ppf > 0) {  // per-face padding: a workgroup's 64*NT positions belong to one face
     a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 64 * NT) * 64 * NT;

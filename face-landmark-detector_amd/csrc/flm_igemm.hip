@@ -454,12 +454,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 template <bool BF, int MMAP, bool RELU>
 static int launch_t(hipStream_t s, const IgemmArgs& a) {
   const size_t lds = sizeof(float) * 4 * TILE_F + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BF, MMAP, RELU>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static FuncAttrOnce attr;
+  FLM_FUNC_ATTR_ONCE(attr, (&igemm_kernel<BF, MMAP, RELU>), lds);
   const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
   igemm_kernel<BF, MMAP, RELU><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
   FLM_LAUNCH_CHECK("igemm_kernel");

@@ -443,29 +443,27 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
   }
 }
 
-static int g_big_enable = 1;  // 0 never, 1 when the tile grid fills the chip, 2 whenever the shape allows (tests),
+// A/B knobs (flm_set_tuning): atomics read at launch time; they never change results or memory layouts
+static std::atomic<int> g_big_enable{1};  // 0 never, 1 when the tile grid fills the chip, 2 whenever the shape allows (tests),
                               // 3 like 1 plus the 256x128 shape for 128-channel layers
-static int g_group_n = 0;     // weight panels per tile group (0: default)
+static std::atomic<int> g_group_n{0};     // weight panels per tile group (0: default)
 void igemm_bf16_big_enable(int on) { g_big_enable = on; }
 void igemm_bf16_group_n(int gn) { g_group_n = gn; }
 
-static int g_big_dma = 1;  // operands reach LDS by buffer_load ... lds (256x256 tiles); 0: through staging registers
+static std::atomic<int> g_big_dma{1};  // operands reach LDS by buffer_load ... lds (256x256 tiles); 0: through staging registers
 void igemm_bf16_big_dma(int on) { g_big_dma = on; }
 
 template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA>
 static int launch_big_t(hipStream_t s, IgemmArgs a) {
   constexpr int BMt = WM * TM * 32, BNt = WN * TN * 32;
   constexpr size_t lds = 2 * (size_t)(BMt + BNt) * ROWB + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    FLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static FuncAttrOnce attr;
+  FLM_FUNC_ATTR_ONCE(attr, (&igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA>), lds);
   a.mtiles = cdiv(a.M, BMt);
   a.ntiles = cdiv(a.cout, BNt);
   // fc6 (position-major): its 100 MB of weights are the big operand, one weight panel per group keeps it in L2
-  a.gn = g_group_n > 0 ? g_group_n : (MMAP == 2 ? 1 : 4);
+  const int group_n = g_group_n.load(std::memory_order_relaxed);
+  a.gn = group_n > 0 ? group_n : (MMAP == 2 ? 1 : 4);
   if (a.gn > a.ntiles) a.gn = a.ntiles;
   a.gm = 32 / a.gn > 0 ? 32 / a.gn : 1;
   const int nblk = cdiv(a.mtiles, a.gm) * a.gm * cdiv(a.ntiles, a.gn) * a.gn;

@@ -174,38 +174,70 @@ int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, in
 }
 
 // ---- crop front-end: K boxes of one frame -> model-size uint8 BGR crops ------------------------------
-// Shape of detect_marks' crop + cv2.resize (reference prediction.py:80-82).  cv2's INTER_LINEAR uses
-// fixed-point weights that cannot be pinned here (cv2 absent): the resample is defined in fp32 instead:
-//   sx = (x + 0.5) * (bw / out_w) - 0.5 + x0   (pixel-centre convention), clamped to the FRAME
-//   bilinear as in the warp, result rounded to nearest-even and clamped to [0,255].
+// detect_marks' `img[y0:y1, x0:x1]` + `cv2.resize(face_img, (W, H))` (reference prediction.py:80-82) and the
+// `cv2.resize(img, (width, height))` of get_image_array (data/generator.py:53), both with cv2's default
+// INTER_LINEAR on uint8.  The arithmetic lives in OpenCV (unpinned dependency, absent here): this kernel restates
+// the published generic algorithm of imgproc/resize.cpp for 8-bit INTER_LINEAR in INTEGER fixed point, so that
+// both sides of the parity test (oracle/warp_ref.py) are exact:
+//   region  = box clipped to the frame (numpy slicing clips the high side; the reference's wrap-around for
+//             negative starts is a defect that is not reproduced), cw x ch pixels at (cx0, cy0)
+//   scale_x = 1.0 / ((double)ow / cw)                                           (double)
+//   fx      = (float)((x + 0.5) * scale_x - 0.5);  sx = floor(fx);  fx -= sx    (product and sum in double)
+//   sx < 0 -> sx = 0, fx = 0;   sx >= cw-1 -> sx = cw-1, fx = 0
+//   a1 = (int)rint(fx * 2048),  a0 = (int)rint((1.f - fx) * 2048)               (11-bit weights, ties to even)
+//   row r:  h_r = S[r][sx]*a0 + S[r][min(sx+1, cw-1)]*a1                        (int32; rows sy and min(sy+1, ch-1))
+//   out = (((b0 * (h_0 >> 4)) >> 16) + ((b1 * (h_1 >> 4)) >> 16) + 2) >> 2      (b0, b1: the same weights along y)
+//   exact 2x downscale in both axes (cw == 2*ow, ch == 2*oh): cv2 switches INTER_LINEAR to the area average
+//   out = (S[2y][2x] + S[2y][2x+1] + S[2y+1][2x] + S[2y+1][2x+1] + 2) >> 2.
+__device__ __forceinline__ void resize_coef(int d, double scale, int n_src, int& s0, int& s1, int& w0, int& w1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { s = 0; f = 0.f; }
+  if (s >= n_src - 1) { s = n_src - 1; f = 0.f; }
+  s0 = s;
+  s1 = min(s + 1, n_src - 1);
+  w0 = (int)rintf((1.f - f) * 2048.f);
+  w1 = (int)rintf(f * 2048.f);
+}
+
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frame, int fh, int fw,
                                                           const int32_t* __restrict__ boxes, uint8_t* __restrict__ out,
                                                           int oh, int ow) {
   const int k = blockIdx.y;
-  const int bx0 = boxes[4 * k + 0], by0 = boxes[4 * k + 1], bx1 = boxes[4 * k + 2], by1 = boxes[4 * k + 3];
-  const float sxs = (float)(bx1 - bx0) / (float)ow, sys = (float)(by1 - by0) / (float)oh;
+  const int cx0 = min(max(boxes[4 * k + 0], 0), fw), cy0 = min(max(boxes[4 * k + 1], 0), fh);
+  const int cx1 = min(max(boxes[4 * k + 2], 0), fw), cy1 = min(max(boxes[4 * k + 3], 0), fh);
+  const int cw = cx1 - cx0, ch = cy1 - cy0;
   const int npix = oh * ow;
+  uint8_t* dst = out + (size_t)k * npix * 3;
+  if (cw <= 0 || ch <= 0) {  // box outside the frame: nothing to sample (cv2.resize raises on an empty crop)
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix * 3; p += gridDim.x * blockDim.x) dst[p] = 0;
+    return;
+  }
+  const uint8_t* src = frame + ((size_t)cy0 * fw + cx0) * 3;
+  const size_t pitch = (size_t)fw * 3;
+  const bool area2 = (cw == 2 * ow) && (ch == 2 * oh);
+  const double scale_x = 1.0 / ((double)ow / (double)cw), scale_y = 1.0 / ((double)oh / (double)ch);
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
     const int x = p % ow, y = p / ow;
-    float xs = fmaf((float)x + 0.5f, sxs, -0.5f) + (float)bx0;
-    float ys = fmaf((float)y + 0.5f, sys, -0.5f) + (float)by0;
-    xs = fminf(fmaxf(xs, 0.f), (float)(fw - 1));
-    ys = fminf(fmaxf(ys, 0.f), (float)(fh - 1));
-    const float xf = floorf(xs), yf = floorf(ys);
-    const float fx = xs - xf, fy = ys - yf;
-    const int x0 = (int)xf, y0 = (int)yf;
-    const int x1 = min(x0 + 1, fw - 1), y1 = min(y0 + 1, fh - 1);
-    const uint8_t* r0 = frame + ((size_t)y0 * fw) * 3;
-    const uint8_t* r1 = frame + ((size_t)y1 * fw) * 3;
-    uint8_t* d = out + ((size_t)k * npix + p) * 3;
+    uint8_t* d = dst + (size_t)p * 3;
+    if (area2) {
+      const uint8_t* r0 = src + (size_t)(2 * y) * pitch + (size_t)(2 * x) * 3;
+      const uint8_t* r1 = r0 + pitch;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[c] = (uint8_t)(((int)r0[c] + (int)r0[3 + c] + (int)r1[c] + (int)r1[3 + c] + 2) >> 2);
+      continue;
+    }
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    resize_coef(x, scale_x, cw, x0, x1, a0, a1);
+    resize_coef(y, scale_y, ch, y0, y1, b0, b1);
+    const uint8_t* r0 = src + (size_t)y0 * pitch;
+    const uint8_t* r1 = src + (size_t)y1 * pitch;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c];
-      const float p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
-      const float top = fmaf(fx, p01 - p00, p00);
-      const float bot = fmaf(fx, p11 - p10, p10);
-      const float v = fmaf(fy, bot - top, top);
-      d[c] = (uint8_t)fminf(fmaxf(rintf(v), 0.f), 255.f);
+      const int h0 = (int)r0[x0 * 3 + c] * a0 + (int)r0[x1 * 3 + c] * a1;
+      const int h1 = (int)r1[x0 * 3 + c] * a0 + (int)r1[x1 * 3 + c] * a1;
+      d[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
     }
   }
 }

@@ -31,6 +31,8 @@ class CapturedPipeline:
         self.template = torch.as_tensor(tm, dtype=torch.float64).to(dev)
         self.scale = (model.input_width / model.output_width, model.input_height / model.output_height)
         self.crops = torch.zeros((self.n, h, w, 3), dtype=torch.uint8, device=dev)
+        # the graph bakes raw pointers into its kernel arguments: it owns its workspace (the model's cache may evict)
+        self.workspace = model.new_workspace(self.n, "landmarks", self.n_points)
         # warm-up on a side stream: first-launch work (function attributes, workspace allocation) must not be captured
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -44,7 +46,8 @@ class CapturedPipeline:
             self.landmarks, self.aligned, self.m = self._sequence()
 
     def _sequence(self):
-        lm = self.model.forward_device(self.crops, "landmarks", n_points=self.n_points, thresh=self.thresh)
+        lm = self.model.forward_device(self.crops, "landmarks", n_points=self.n_points, thresh=self.thresh,
+                                       workspace=self.workspace)
         aligned, m = alignment.align_device(self.crops, lm, self.template, self.out_hw[0], self.out_hw[1], self.scale)
         return lm, aligned, m
 

@@ -10,22 +10,16 @@ from .fcn import (fcn_8, fcn_32, fcn_8_vgg, fcn_32_vgg, fcn_8_mobilenet, fcn_32_
                   fcn_32_resnet50)
 
 
-def _not_built(name, why):
-    def ctor(*a, **k):
-        raise NotImplementedError("%s is not built: %s" % (name, why))
-    return ctor
-
-
-_BACKBONE = "residual bottleneck blocks (strided convs, 3x3 s2 max-pool, adds) are not built; SURVEY.md section 8 row F4"
-
 LANDMARKS_MODELS = {
     "fcn_8": fcn_8,
     "fcn_32": fcn_32,
     "default": fcn_8,
-    "fcn_8_resnet50": fcn_8_resnet50,     # likewise, fp32
+    # the reference's keys (basic_models.py:59-64), every one built WITHOUT the ImageNet download its constructor
+    # performs by default (`pretrained=None` graphs); fp32 and bf16
+    "fcn_8_resnet50": fcn_8_resnet50,
     "fcn_32_resnet50": fcn_32_resnet50,
-    "fcn_8_mobilenet": fcn_8_mobilenet,   # likewise, fp32
+    "fcn_8_mobilenet": fcn_8_mobilenet,
     "fcn_32_mobilenet": fcn_32_mobilenet,
-    "fcn_8_vgg": fcn_8_vgg,      # built without the ImageNet download (pretrained=None)
+    "fcn_8_vgg": fcn_8_vgg,
     "fcn_32_vgg": fcn_32_vgg,
 }

@@ -10,6 +10,7 @@ in libflm_hip.so; tensors live in HBM as torch tensors (allocation + streams onl
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 
 import numpy as np
@@ -51,7 +52,12 @@ class Fcn8Model:
         self.output_height = self.input_height + self._grid_growth
         self.output_width = self.input_width + self._grid_growth
         self._packed = None
-        self._ws = {}
+        # cached workspaces, least recently used first; one entry is dropped at a time and never one a caller still
+        # holds (graphs.CapturedPipeline owns its workspace outright, see new_workspace)
+        self._ws = collections.OrderedDict()
+        self._ws_cap = 4
+        # per-model defaults of the per-call options that change the workspace layout (include/flm.h: flm_forward_opts)
+        self.forward_opts = {}
         # the kernels address activations with 32-bit byte offsets: the largest tensor (f1, 64 channels at
         # half resolution) bounds the faces per launch; larger batches are processed in slices
         es = 4 if dtype == "f32" else 2
@@ -122,29 +128,54 @@ class Fcn8Model:
         self._packed = packed
 
     # ---- forward ------------------------------------------------------------------------------
-    def _workspace(self, n, out_mode, dmode, npts):
+    def _opts(self, opts):
+        """flm_forward_opts for a call: the model's defaults overridden by `opts` (a dict or None)."""
+        merged = dict(self.forward_opts)
+        merged.update(opts or {})
+        return _lib.ForwardOpts.make(**merged)
+
+    def workspace_bytes(self, n, out="probs", n_points=0, opts=None):
+        om = _OUT[out]
+        dmode, npts = decode_mode_of(n_points) if om == _lib.OUT_LANDMARKS else (0, 0)
+        fo = self._opts(opts)
+        nbytes = _lib.load().flm_fcn_workspace_bytes_opts(self._arch, n, self.input_height, self.input_width,
+                                                          self.n_classes, self._dt, om, dmode, npts, C.byref(fo))
+        if nbytes == 0:
+            raise _lib.FlmError("workspace query failed: %s" % _lib.load().flm_last_error().decode())
+        return int(nbytes)
+
+    def new_workspace(self, n, out="probs", n_points=0, opts=None):
+        """A workspace the CALLER owns (pass it as forward_device(..., workspace=ws)): what a captured HIP graph or any
+        other holder of raw pointers must use, since cached workspaces may be evicted."""
         import torch
-        key = (n, out_mode, dmode, npts)
+        return torch.empty(self.workspace_bytes(n, out, n_points, opts), dtype=torch.uint8, device=_lib.require_gpu())
+
+    def _workspace(self, n, out_mode, dmode, npts, fo):
+        import torch
+        key = (n, out_mode, dmode, npts) + fo.key()
         ws = self._ws.get(key)
-        if ws is None:
-            lib = _lib.load()
-            nbytes = lib.flm_fcn_workspace_bytes(self._arch, n, self.input_height, self.input_width,
-                                                 self.n_classes, self._dt, out_mode, dmode, npts)
-            if nbytes == 0:
-                raise _lib.FlmError("workspace query failed: %s" % lib.flm_last_error().decode())
-            if len(self._ws) > 4:
-                self._ws.clear()
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=_lib.require_gpu())
-            self._ws[key] = ws
+        if ws is not None:
+            self._ws.move_to_end(key)
+            return ws
+        nbytes = _lib.load().flm_fcn_workspace_bytes_opts(self._arch, n, self.input_height, self.input_width,
+                                                          self.n_classes, self._dt, out_mode, dmode, npts, C.byref(fo))
+        if nbytes == 0:
+            raise _lib.FlmError("workspace query failed: %s" % _lib.load().flm_last_error().decode())
+        while len(self._ws) >= self._ws_cap:   # single-entry LRU eviction
+            self._ws.popitem(last=False)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=_lib.require_gpu())
+        self._ws[key] = ws
         return ws
 
-    def forward_device(self, x, out="probs", n_points=0, thresh=0.0, out_tensor=None):
+    def forward_device(self, x, out="probs", n_points=0, thresh=0.0, out_tensor=None, workspace=None, opts=None):
         """One launch sequence on the current stream; everything stays in HBM.
 
         x: torch CUDA tensor [N,H,W,3], uint8 (raw BGR crop: preprocess fused) or float32
            (already preprocessed, what model.predict receives).
         out: "probs" float32 [N,H'*W',C] | "classmap" int32 [N,H',W'] |
              "landmarks" float64 [N,C,2] | "logits" float32 [N,H',W',C].
+        workspace: a caller-owned workspace from `new_workspace` (same n / out / n_points / opts); default: a cached one.
+        opts: dict of flm_forward_opts fields (landmark_candidates, candidate_sub_phases, candidate_cap_div).
         """
         import torch
         lib = _lib.load()
@@ -182,25 +213,30 @@ class Fcn8Model:
         elif tuple(out_tensor.shape) != shape or out_tensor.dtype != dt or not out_tensor.is_contiguous():
             raise ValueError("out_tensor must be contiguous %s %s" % (shape, dt))
         if n > self.max_batch:   # slice the batch (contiguous outputs, same stream)
+            if workspace is not None:
+                raise ValueError("a caller-owned workspace cannot serve a batch beyond max_batch (%d)" % self.max_batch)
             for lo in range(0, n, self.max_batch):
                 hi = min(n, lo + self.max_batch)
-                self.forward_device(x[lo:hi], out, n_points, thresh, out_tensor[lo:hi])
+                self.forward_device(x[lo:hi], out, n_points, thresh, out_tensor[lo:hi], opts=opts)
             return out_tensor
-        ws = self._workspace(n, om, dmode, npts)
-        _lib.check(lib.flm_fcn_forward(_lib.stream_ptr(), self._arch, _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
-                                        self.input_height, self.input_width, c, self._dt, om, dmode, npts,
-                                        float(thresh), _lib.ptr(out_tensor), _lib.ptr(ws), ws.numel()),
-                   "flm_fcn_forward")
+        fo = self._opts(opts)
+        ws = workspace if workspace is not None else self._workspace(n, om, dmode, npts, fo)
+        _lib.check(lib.flm_fcn_forward_opts(_lib.stream_ptr(), self._arch, _lib.ptr(self._packed), _lib.ptr(x), fmt, n,
+                                             self.input_height, self.input_width, c, self._dt, om, dmode, npts,
+                                             float(thresh), _lib.ptr(out_tensor), _lib.ptr(ws), ws.numel(),
+                                             C.byref(fo)),
+                   "flm_fcn_forward_opts")
         return out_tensor
 
-    def intermediate(self, name, n, out="probs", n_points=0):
-        """View of a named workspace tensor of the last forward with the same (n, out) (tests)."""
+    def intermediate(self, name, n, out="probs", n_points=0, opts=None, workspace=None):
+        """View of a named workspace tensor of the last forward with the same (n, out, n_points, opts) (tests)."""
         import torch
         lib = _lib.load()
         om = _OUT[out]
         dmode, npts = decode_mode_of(n_points) if om == _lib.OUT_LANDMARKS else (0, 0)
-        off = lib.flm_fcn8_workspace_offset(name.encode(), n, self.input_height, self.input_width, self.n_classes,
-                                            self._dt, om, dmode, npts)
+        fo = self._opts(opts)
+        off = lib.flm_fcn8_workspace_offset_opts(name.encode(), n, self.input_height, self.input_width, self.n_classes,
+                                                 self._dt, om, dmode, npts, C.byref(fo))
         if off < 0:
             raise KeyError(name)
         h, w = self.input_height, self.input_width
@@ -213,7 +249,7 @@ class Fcn8Model:
                   "seg_feats": (h // 8, w // 8, cp),
                   "probs": (self.output_height * self.output_width, self.n_classes)}
         shp = (n,) + shapes[name]
-        ws = self._workspace(n, om, dmode, npts)
+        ws = workspace if workspace is not None else self._workspace(n, om, dmode, npts, fo)
         cnt = int(np.prod(shp))
         if bf and name in ("f1", "f2", "f3", "f4", "f5", "fc6", "fc7"):   # stored in the operand type
             return ws[off:off + 2 * cnt].view(torch.bfloat16).view(shp).float()
@@ -248,7 +284,7 @@ class Fcn32Model(Fcn8Model):
     _grid_growth = 32
     _fcn32 = True
 
-    def intermediate(self, name, n, out="probs", n_points=0):
+    def intermediate(self, name, n, out="probs", n_points=0, opts=None, workspace=None):
         raise NotImplementedError("workspace views are exposed for fcn_8 only")
 
 
@@ -265,7 +301,7 @@ class Fcn8VggModel(Fcn8Model):
     _arch = _lib.ARCH_FCN8_VGG
     _enc_layers = _VGG_LAYERS
 
-    def intermediate(self, name, n, out="probs", n_points=0):
+    def intermediate(self, name, n, out="probs", n_points=0, opts=None, workspace=None):
         raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")
 
 
@@ -303,7 +339,7 @@ class Fcn8MobilenetModel(Fcn8Model):
     def __init__(self, n_classes, input_height=224, input_width=224, channels=3, dtype="f32"):
         super().__init__(n_classes, input_height, input_width, channels, dtype)
 
-    def intermediate(self, name, n, out="probs", n_points=0):
+    def intermediate(self, name, n, out="probs", n_points=0, opts=None, workspace=None):
         raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")
 
 
@@ -338,7 +374,7 @@ class Fcn8Resnet50Model(Fcn8Model):
     _arch = _lib.ARCH_FCN8_RESNET50
     _enc_layers = _RESNET_LAYERS
 
-    def intermediate(self, name, n, out="probs", n_points=0):
+    def intermediate(self, name, n, out="probs", n_points=0, opts=None, workspace=None):
         raise NotImplementedError("workspace views are exposed for the vanilla fcn_8 only")
 
 

@@ -218,6 +218,8 @@ def detect_marks_batch(img, model, faces, n_points=4, thresh=0.0):
     """All faces of one frame in one batch: crop -> FCN -> decode -> back-projection
     (prediction.py:76-94).  Returns uint [K,C,2] image coordinates."""
     import torch
+    if len(faces) == 0:   # a frame without faces: the reference's per-face loop (prediction.py:105-107) does nothing
+        return np.zeros((0, model.n_classes, 2), np.uint)
     dev = _lib.require_gpu()
     frame = torch.from_numpy(np.ascontiguousarray(img)).to(dev) if not isinstance(img, torch.Tensor) else img
     boxes = face_boxes(faces)
@@ -237,3 +239,27 @@ def detect_marks_batch(img, model, faces, n_points=4, thresh=0.0):
 def detect_marks(img, model, face):
     """prediction.py:16-96 for one face; `model` is this package's FCN-8 model object."""
     return detect_marks_batch(img, model, [face])[0]
+
+
+def video_predict(facedetector_fn, landmark_model, frames=None, on_frame=None, n_points=4, thresh=0.0):
+    """prediction.py:99-113: per frame `rects = facedetector_fn(img)`, landmarks of every face, `draw_marks(img, marks)`.
+
+    The reference reads camera 0 through cv2.VideoCapture and shows each frame with cv2.imshow until 'q' is pressed;
+    neither exists here, so the frame source and the sink are arguments: `frames` is any iterable of uint8 BGR
+    [H,W,3] arrays, `on_frame(img, marks)` receives the annotated frame (marks: uint [K,C,2], K may be 0) and ends
+    the loop by returning False -- the 'q' key.  All faces of a frame go through ONE batched launch sequence
+    (`detect_marks_batch`) instead of the reference's per-face model calls.  Returns the number of frames processed."""
+    from .utils.plots import draw_marks
+    if frames is None:
+        raise ValueError("video_predict needs `frames` (an iterable of BGR uint8 images): there is no camera capture "
+                         "without cv2 (prediction.py:100)")
+    count = 0
+    for img in frames:
+        rects = facedetector_fn(img)
+        marks = detect_marks_batch(img, landmark_model, list(rects), n_points=n_points, thresh=thresh)
+        for k in range(marks.shape[0]):
+            draw_marks(img, marks[k])
+        count += 1
+        if on_frame is not None and on_frame(img, marks) is False:
+            break
+    return count

@@ -2,17 +2,40 @@
 
 Same names and argument meaning.  The reference's `transfer_xy_coord` passes
 `(n_points, thresh)` into `get_average_xy`'s `(height, width)` slots (:98), so as shipped
-every call behaves as n_points=4, thresh=0.  This module honours the documented arguments;
-`as_shipped=True` (or the module switch below) reproduces the shipped behaviour exactly.
+EVERY call decodes with n_points=4, thresh=0, whatever the caller passed.  Drop-in rule here:
+  * a call that relies on the defaults -- `transfer_target(y)`, `transfer_xy_coord(hm)` -- returns
+    what the reference returns (top-4, thresh 0);
+  * a call that passes `n_points` / `thresh` explicitly gets what it asked for (the reference would
+    silently ignore the arguments) and a one-time warning says so;
+  * `as_shipped=True` forces the reference's behaviour, `as_shipped=False` the documented one.
 Device limits: 1 <= n_points <= 64 in top-n mode, <= 96 landmarks per map.
 """
 from __future__ import annotations
+
+import warnings
 
 import numpy as np
 
 from .. import _lib
 
-REFERENCE_POSITIONAL_SLIP = False
+_UNSET = object()
+_warned = False
+
+
+def _resolve(n_points, thresh, as_shipped, dflt_n, dflt_t):
+    """(n_points, thresh) a decode call runs with; see the module docstring."""
+    global _warned
+    explicit = n_points is not _UNSET or thresh is not _UNSET
+    if as_shipped is None:
+        as_shipped = not explicit
+        if explicit and not _warned:
+            _warned = True
+            warnings.warn("flm_amd.utils.metrics: n_points / thresh are honoured here; the reference as shipped ignores "
+                          "them and always decodes top-4 with thresh 0 (utils/metrics.py:98) -- pass as_shipped=True "
+                          "for that behaviour", stacklevel=3)
+    if as_shipped:
+        return 4, 0
+    return (dflt_n if n_points is _UNSET else n_points), (dflt_t if thresh is _UNSET else thresh)
 
 
 def decode_device(hm, n_points=4, thresh=0.0, out=None):
@@ -51,19 +74,17 @@ def get_average_xy(hmi, height=96, width=96, n_points=4, thresh=0):
     return [xy[0], xy[1]]
 
 
-def transfer_xy_coord(hm, n_points=64, thresh=0.2, as_shipped=None):
-    """utils/metrics.py:83-99: [H,W,L] -> list of 2L floats (x0,y0,x1,y1,...)."""
+def transfer_xy_coord(hm, n_points=_UNSET, thresh=_UNSET, as_shipped=None):
+    """utils/metrics.py:83-99 (documented defaults n_points=64, thresh=0.2): [H,W,L] -> list of 2L floats."""
     hm = np.asarray(hm)
     assert len(hm.shape) == 3
-    return list(transfer_target(hm[None], thresh, n_points, as_shipped)[0])
+    n_points, thresh = _resolve(n_points, thresh, as_shipped, 64, 0.2)
+    return list(transfer_target(hm[None], thresh, n_points, as_shipped=False)[0])
 
 
-def transfer_target(y_pred, thresh=0, n_points=64, as_shipped=None):
-    """utils/metrics.py:102-109: [N,H,W,L] -> float64 [N, 2L]."""
-    if as_shipped is None:
-        as_shipped = REFERENCE_POSITIONAL_SLIP
-    if as_shipped:
-        n_points, thresh = 4, 0
+def transfer_target(y_pred, thresh=_UNSET, n_points=_UNSET, as_shipped=None):
+    """utils/metrics.py:102-109 (documented defaults thresh=0, n_points=64): [N,H,W,L] -> float64 [N, 2L]."""
+    n_points, thresh = _resolve(n_points, thresh, as_shipped, 64, 0)
     import torch
     if isinstance(y_pred, torch.Tensor):
         hm = y_pred if y_pred.is_cuda else y_pred.to(_lib.require_gpu())

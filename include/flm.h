@@ -17,6 +17,12 @@
  *    *_workspace_bytes query.
  *  - return value: 0 = FLM_OK, negative = error; flm_last_error() returns a
  *    thread-local message for the last failing call on this thread.
+ *  - reentrancy: calls on different streams may run concurrently from different threads.
+ *    Process state is limited to (1) the thread-local error string, (2) the A/B
+ *    performance knobs of flm_set_tuning -- atomic integers read at launch time that
+ *    never change results or memory layouts, (3) the measurement hook flm_profile_*
+ *    (off by default; a measurement aid, NOT thread-safe).  Everything that changes
+ *    results' provenance or the workspace layout is an argument (flm_forward_opts).
  *  - layouts are NHWC ("channels_last", networks/config.py:5) throughout.
  */
 #ifndef FLM_H_
@@ -29,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FLM_ABI_VERSION 1
+#define FLM_ABI_VERSION 2
 
 typedef void* flm_stream_t; /* hipStream_t */
 
@@ -172,9 +178,35 @@ int flm_fcn_forward(flm_stream_t stream, int arch, const void* packed_dev, const
                     int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
                     int n_points, float thresh, void* out_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* Per-call options of the forward that change the WORKSPACE LAYOUT (never the results): pass the same struct to the
+ * workspace query and to the forward.  NULL = defaults.  Initialise with flm_forward_opts_init (sets struct_size, which
+ * lets the struct grow without breaking callers).
+ *   landmark_candidates   1 (default): FLM_OUT_LANDMARKS with top-n, n <= 32, on the 68-class FCN-8 kernels selects
+ *                         from candidate keys emitted by the last transposed conv instead of materialising the
+ *                         [N,H'*W',C] probabilities (bit-identical landmarks, gated fallback); 0: always materialise
+ *                         and decode (the decode of utils/metrics.py:102-109 on model.predict's output, literally)
+ *   candidate_sub_phases  phases per tile in that path's sampling launch (1..16; 0 = by n_points: 4 up to n = 8, 6 up
+ *                         to 15, 8 beyond)
+ *   candidate_cap_div     shrink the candidate lists by this factor (>= 1; tests of the overflow fallback) */
+typedef struct flm_forward_opts {
+  uint32_t struct_size;
+  int32_t landmark_candidates;
+  int32_t candidate_sub_phases;
+  int32_t candidate_cap_div;
+} flm_forward_opts;
+void flm_forward_opts_init(flm_forward_opts* opts);
+size_t flm_fcn_workspace_bytes_opts(int arch, int n, int h, int w, int n_classes, int dtype, int out_mode,
+                                    int decode_mode, int n_points, const flm_forward_opts* opts);
+int flm_fcn_forward_opts(flm_stream_t stream, int arch, const void* packed_dev, const void* x_dev, int in_format,
+                         int n, int h, int w, int n_classes, int dtype, int out_mode, int decode_mode,
+                         int n_points, float thresh, void* out_dev, void* workspace_dev, size_t workspace_bytes,
+                         const flm_forward_opts* opts);
+int64_t flm_fcn8_workspace_offset_opts(const char* name, int n, int h, int w, int n_classes, int dtype,
+                                       int out_mode, int decode_mode, int n_points, const flm_forward_opts* opts);
+
 /* One named Conv2D layer of the model in isolation ("enc2".."enc5" with BN+ReLU+pool fused,
  * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  Used by
- * the layer parity tests and by bench.py to time the dominant kernel on its own stream. */
+ * tools/debug_layer.py to run and time one layer in isolation. */
 int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const void* x_dev,
                        void* y_dev, int n, int h, int w, int n_classes, int dtype);
 
@@ -187,22 +219,16 @@ int flm_profile_enable(int max_records);
 /* Bracket only the launches of one layer ("fc6", ...; NULL or "" = every launch).  Every event pair costs a few
  * microseconds of stream time, so a timed region that only needs the dominant kernel's duration filters on it. */
 int flm_profile_filter(const char* layer);
-/* Performance knobs (never change results); key "none" is always accepted, unknown keys fail.  Process-global,
- * read at launch time; meant for A/B runs (tools/tune.py) and for tests that force a code path:
+/* A/B performance knobs: they never change results or memory layouts; key "none" is always accepted, unknown keys
+ * fail.  Atomic integers read at launch time; meant for A/B runs (tools/tune.py) and for tests that force a code path:
  *   "bf16_big_tiles"        0 off | 1 auto (default) | 2 whenever the shape allows | 3 auto + 256x128 tiles
  *                           256-row bf16 implicit-GEMM tiles (csrc/flm_igemm_bf16.hip)
  *   "bf16_lds_dma"          1 (default): the 256x256 tiles fetch their operands with buffer_load ... lds (no staging
  *                           registers, no LDS write pass); 0: global -> registers -> LDS
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
- *   "landmark_candidates"   0: FLM_OUT_LANDMARKS always materialises the probabilities and decodes them;
- *                           1 (default): top-n with n <= 32 on the 68-class FCN-8 kernels selects from candidate
- *                           keys emitted by the last transposed conv (bit-identical results, gated fallback)
- *   "candidate_sub_phases"  phases per tile in that path's sampling launch (1..16; default 0 = by n_points: 4 up to
- *                           n = 8, 6 up to 15, 8 beyond)
- *   "candidate_cap_div"     shrink the candidate lists by this factor (tests of the overflow fallback)
- * "landmark_candidates" and "candidate_*" change the workspace layout: query flm_*_workspace_bytes after
- * setting them. */
+ * The options that change the workspace layout ("landmark_candidates", "candidate_*") are per-call arguments:
+ * flm_forward_opts above. */
 int flm_set_tuning(const char* key, int value);
 /* Diagnostics for developers ("igemm_occupancy", arg = dynamic LDS bytes -> workgroups per CU). */
 int flm_debug_query(const char* key, int arg);
@@ -243,10 +269,13 @@ int flm_warp_affine(flm_stream_t stream, const void* src_dev /*[N,Hs,Ws,3]*/, in
                     int hs, int ws, const float* m_dev /*[N,2,3] src->dst*/,
                     float* dst_dev /*[N,Hd,Wd,3]*/, int hd, int wd);
 
-/* ---- crop front-end (detect_marks pre-processing, prediction.py:76-83) -----------
- * Bilinear crop+resize of K boxes from one uint8 BGR frame into the model's input
- * batch (uint8 BGR [K,out_h,out_w,3]); boxes are (x0,y0,x1,y1) int32, already squared by
- * the host-side box maths. */
+/* ---- crop front-end (detect_marks pre-processing, prediction.py:76-83; get_image_array's resize,
+ * data/generator.py:53) ---------------------------------------------------------------------------
+ * `img[y0:y1, x0:x1]` + `cv2.resize(., (out_w, out_h))` (default INTER_LINEAR on uint8) for K boxes of one
+ * uint8 BGR frame, into the model's input batch (uint8 BGR [K,out_h,out_w,3]); boxes are (x0,y0,x1,y1)
+ * int32, already squared by the host-side box maths, clipped to the frame here (a box that misses the frame
+ * gives zeros).  Integer fixed point: OpenCV's 11-bit-weight algorithm restated (csrc/flm_misc.hip states
+ * every operation), bit-exact against oracle/warp_ref.py; parity with the cv2 binary itself is unpinned. */
 int flm_crop_resize(flm_stream_t stream, const uint8_t* frame_dev, int fh, int fw,
                     const int32_t* boxes_dev /*[K,4]*/, int k, uint8_t* out_dev, int out_h, int out_w);
 

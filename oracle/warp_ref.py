@@ -9,9 +9,10 @@ operation in the kernel comments of csrc/flm_misc.hip; this file restates it in 
 reference's only affine warp, data/generator.py:192-200) through fixtures generated with the
 second interpreter in the build container.
 
-fp32 fused multiply-add is emulated as float32(float64(a)*float64(b) + float64(c)); the product
-is exact in float64, so the only difference from a hardware fma is a possible double rounding
-(<= 1 ULP, the tolerance the GPU parity test uses).
+fp32 fused multiply-add is restated EXACTLY: the product of two float32 is exact in float64; the sum with the
+addend is taken with its rounding error (TwoSum), and where the float64 sum sits exactly on a float32 rounding
+boundary the error term decides the direction -- so `fma()` below returns the correctly rounded float32 of a*b+c, as
+the hardware instruction does.  The crop/resize is integer fixed point on both sides (bit-exact by construction).
 """
 from __future__ import annotations
 
@@ -21,7 +22,20 @@ f32 = np.float32
 
 
 def fma(a, b, c):
-    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+    """Correctly rounded float32 fused multiply-add of float32 operands (see the module docstring)."""
+    a, b, c = (np.asarray(v, np.float32).astype(np.float64) for v in (a, b, c))
+    p = a * b                                   # exact: 24 + 24 significant bits
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)             # TwoSum: p + c == s + err exactly
+    r = s.astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        hi = np.nextafter(r, np.float32(np.inf))
+        lo = np.nextafter(r, np.float32(-np.inf))
+        r64 = r.astype(np.float64)
+        tie_hi = (s == (r64 + hi.astype(np.float64)) / 2) & (err > 0)   # exact value lies above the midpoint
+        tie_lo = (s == (r64 + lo.astype(np.float64)) / 2) & (err < 0)
+    return np.where(tie_hi, hi, np.where(tie_lo, lo, r)).astype(np.float32)
 
 
 def similarity_ref(lm: np.ndarray, tmpl: np.ndarray) -> np.ndarray:
@@ -90,19 +104,53 @@ def warp_affine_ref(src: np.ndarray, m: np.ndarray, hd: int, wd: int) -> np.ndar
     return out
 
 
+def _resize_coef(n_dst: int, n_src: int):
+    """Per destination index: (s0, s1, w0, w1) of OpenCV's 8-bit INTER_LINEAR (imgproc/resize.cpp, generic path):
+    scale = 1/(n_dst/n_src) in double; f = float((d + 0.5)*scale - 0.5); s = floor(f); f -= s; clamped at both ends;
+    11-bit weights w1 = rint(f*2048), w0 = rint((1-f)*2048) (cvRound: ties to even)."""
+    scale = np.float64(1.0) / (np.float64(n_dst) / np.float64(n_src))
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    low, high = s < 0, s >= n_src - 1
+    s = np.where(low, 0, np.where(high, n_src - 1, s))
+    f = np.where(low | high, f32(0), f).astype(np.float32)
+    w0 = np.rint((f32(1) - f) * f32(2048)).astype(np.int64)
+    w1 = np.rint(f * f32(2048)).astype(np.int64)
+    return s, np.minimum(s + 1, n_src - 1), w0, w1
+
+
+def resize_u8_ref(src: np.ndarray, oh: int, ow: int) -> np.ndarray:
+    """`cv2.resize(src, (ow, oh))` for uint8 [h,w,c] with the default INTER_LINEAR, as OpenCV's generic code computes
+    it (data/generator.py:53, prediction.py:82).  Integer arithmetic throughout:
+      horizontal  h = S[x0]*a0 + S[x1]*a1                      (int32, weights sum to 2048)
+      vertical    out = (((b0*(h0 >> 4)) >> 16) + ((b1*(h1 >> 4)) >> 16) + 2) >> 2
+      exact 2x downscale in both axes -> INTER_AREA: (S00 + S01 + S10 + S11 + 2) >> 2."""
+    ch, cw = src.shape[:2]
+    s = src.astype(np.int64)
+    if cw == 2 * ow and ch == 2 * oh:
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    x0, x1, a0, a1 = _resize_coef(ow, cw)
+    y0, y1, b0, b1 = _resize_coef(oh, ch)
+    hrow = s[:, x0] * a0[None, :, None] + s[:, x1] * a1[None, :, None]            # [ch, ow, c]
+    h0, h1 = hrow[y0] >> 4, hrow[y1] >> 4
+    out = (((b0[:, None, None] * h0) >> 16) + ((b1[:, None, None] * h1) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
 def crop_resize_ref(frame: np.ndarray, boxes: np.ndarray, oh: int, ow: int) -> np.ndarray:
-    """frame [H,W,3] uint8, boxes int [K,4] (x0,y0,x1,y1) -> uint8 [K,oh,ow,3] (csrc/flm_misc.hip)."""
-    k = boxes.shape[0]
-    out = np.zeros((k, oh, ow, 3), np.uint8)
-    y, x = np.mgrid[0:oh, 0:ow]
-    for i in range(k):
+    """frame [H,W,3] uint8, boxes int [K,4] (x0,y0,x1,y1) -> uint8 [K,oh,ow,3]: `img[y0:y1, x0:x1]` then
+    `cv2.resize(..., (ow, oh))` (prediction.py:80-82); the box is clipped to the frame (csrc/flm_misc.hip), an empty
+    intersection gives zeros."""
+    fh, fw = frame.shape[:2]
+    out = np.zeros((boxes.shape[0], oh, ow, 3), np.uint8)
+    for i in range(boxes.shape[0]):
         bx0, by0, bx1, by1 = [int(v) for v in boxes[i]]
-        sxs = f32(bx1 - bx0) / f32(ow)
-        sys_ = f32(by1 - by0) / f32(oh)
-        xs = (fma(x.astype(np.float32) + f32(0.5), sxs, f32(-0.5)) + f32(bx0)).astype(np.float32)
-        ys = (fma(y.astype(np.float32) + f32(0.5), sys_, f32(-0.5)) + f32(by0)).astype(np.float32)
-        v = _bilinear(frame.astype(np.float32), xs, ys)
-        out[i] = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+        cx0, cx1 = min(max(bx0, 0), fw), min(max(bx1, 0), fw)
+        cy0, cy1 = min(max(by0, 0), fh), min(max(by1, 0), fh)
+        if cx1 > cx0 and cy1 > cy0:
+            out[i] = resize_u8_ref(frame[cy0:cy1, cx0:cx1], oh, ow)
     return out
 
 

@@ -50,34 +50,42 @@ def test_size_queries_answer_without_a_gpu():
 
 
 def test_tuning_knobs_and_workspace_layout():
-    """flm_set_tuning: documented keys are accepted, unknown keys and bad values fail with a message; the candidate
-    landmark path (flm.h) adds its lists to the workspace only where it applies (top-n <= 32, 68 classes, fcn_8)."""
+    """flm_set_tuning: documented A/B keys are accepted, unknown keys and bad values fail with a message.  What changes the
+    workspace layout is NOT process state: the candidate landmark path is chosen per call by flm_forward_opts, and adds its
+    lists to the workspace only where it applies (top-n <= 32, 68 classes, fcn_8)."""
+    import ctypes as C
     from flm_amd import _lib
     lib = _lib.load()
-    for key, val in ((b"none", 0), (b"bf16_big_tiles", 1), (b"bf16_group_n", 0), (b"bf16_lds_dma", 1), (b"bf16_conv3_halo", 1),
-                     (b"landmark_candidates", 1), (b"candidate_sub_phases", 4), (b"candidate_sub_phases", 0),
-                     (b"candidate_cap_div", 1)):
+    for key, val in ((b"none", 0), (b"bf16_big_tiles", 1), (b"bf16_group_n", 0), (b"bf16_lds_dma", 1), (b"bf16_conv3_halo", 1)):
         assert lib.flm_set_tuning(key, val) == 0, key
     assert lib.flm_set_tuning(b"no_such_knob", 1) != 0 and b"no_such_knob" in lib.flm_last_error()
     assert lib.flm_set_tuning(b"bf16_group_n", 3) != 0
-    assert lib.flm_set_tuning(b"candidate_sub_phases", 17) != 0 and lib.flm_set_tuning(b"candidate_sub_phases", -1) != 0
-    assert lib.flm_set_tuning(b"candidate_cap_div", 0) != 0
-    args = (8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN)
-    try:
-        on = lib.flm_fcn8_workspace_bytes(*args, 4)
-        assert lib.flm_set_tuning(b"landmark_candidates", 0) == 0
-        off = lib.flm_fcn8_workspace_bytes(*args, 4)
-        assert on > off > 0
-        assert lib.flm_set_tuning(b"landmark_candidates", 1) == 0
-        assert lib.flm_fcn8_workspace_bytes(*args, 64) == lib.flm_fcn8_workspace_bytes(*args, 64)  # n > 32: no lists
-        big_n = lib.flm_fcn8_workspace_bytes(*args, 64)
-        lib.flm_set_tuning(b"landmark_candidates", 0)
-        assert big_n == lib.flm_fcn8_workspace_bytes(*args, 64)
-        lib.flm_set_tuning(b"landmark_candidates", 1)
-        # all-pixel mode and other class counts keep the materialised path
-        assert lib.flm_fcn8_workspace_bytes(8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_ALL, 0) < on
-    finally:
-        lib.flm_set_tuning(b"landmark_candidates", 1)
+    for key in (b"landmark_candidates", b"candidate_sub_phases", b"candidate_cap_div"):   # moved into the call
+        assert lib.flm_set_tuning(key, 1) != 0 and b"flm_forward_opts" in lib.flm_last_error()
+    dflt = _lib.ForwardOpts.make()
+    assert dflt.struct_size == C.sizeof(_lib.ForwardOpts) == 16 and dflt.key() == (1, 0, 1)
+    off_o = _lib.ForwardOpts.make(landmark_candidates=0)
+    args = (_lib.ARCH_FCN8, 8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN)
+    q = lambda npts, o: lib.flm_fcn_workspace_bytes_opts(*args, npts, C.byref(o) if o is not None else None)
+    on, off = q(4, dflt), q(4, off_o)
+    assert on > off > 0
+    assert q(4, None) == on == lib.flm_fcn_workspace_bytes(*args, 4) == lib.flm_fcn8_workspace_bytes(*args[1:], 4)
+    assert q(64, dflt) == q(64, off_o)                      # n > 32: no lists either way
+    assert q(4, _lib.ForwardOpts.make(candidate_cap_div=4)) < on
+    assert q(25, _lib.ForwardOpts.make(candidate_sub_phases=8)) != q(25, _lib.ForwardOpts.make(candidate_sub_phases=2))
+    # all-pixel mode keeps the materialised path
+    assert lib.flm_fcn_workspace_bytes_opts(_lib.ARCH_FCN8, 8, 256, 256, 68, _lib.FLM_F32, _lib.OUT_LANDMARKS,
+                                            _lib.DECODE_ALL, 0, C.byref(dflt)) < on
+    # invalid option structs size nothing and say why
+    bad = _lib.ForwardOpts.make()
+    bad.struct_size = 4
+    assert q(4, bad) == 0 and b"struct_size" in lib.flm_last_error()
+    for field, val in (("candidate_sub_phases", 17), ("candidate_sub_phases", -1), ("candidate_cap_div", 0)):
+        bad = _lib.ForwardOpts.make()
+        setattr(bad, field, val)
+        assert q(4, bad) == 0
+    assert lib.flm_fcn8_workspace_offset_opts(b"cand_keys", *args[1:], 4, C.byref(off_o)) == -1
+    assert lib.flm_fcn8_workspace_offset_opts(b"cand_keys", *args[1:], 4, C.byref(dflt)) > 0
 
 
 def test_null_arguments_are_rejected_not_dereferenced():

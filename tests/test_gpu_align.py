@@ -1,7 +1,8 @@
 """GPU parity: similarity estimate, alignment warp and crop front-end vs oracle/warp_ref.py.
 
-Bars (BASELINE.json north_star): warped pixels within 1 ULP of the CPU restatement (the
-restatement emulates fma through float64, so a double rounding may move a value by one ULP).
+Bars (BASELINE.json north_star): warped pixels within 1 ULP of the CPU restatement -- whose fma is correctly
+rounded (oracle/warp_ref.py), so no escape for small values is needed; the similarity fit (float64, sequential sums
+on both sides) and the crop/resize (integer fixed point on both sides) are bit-exact.
 """
 import os
 
@@ -50,9 +51,9 @@ def test_warp_within_one_ulp(A, u8):
     exp = warp_ref.warp_affine_ref(src, m, hd, wd)
     got = A.warp_device(torch.from_numpy(src).cuda(), torch.from_numpy(m).cuda(), hd, wd).cpu().numpy()
     assert got.shape == exp.shape
-    # 1 ULP, or an absolute 1e-5 on results that cancel to (near) zero
-    bad = (ulp_diff(got, exp) > 1) & (np.abs(got - exp) > 1e-5)
-    assert not bad.any(), (int(bad.sum()), float(np.abs(got - exp).max()))
+    u = ulp_diff(got, exp)
+    print("warp (u8=%s): %d of %d values differ from the restatement, max %d ULP" % (u8, int((u > 0).sum()), u.size, int(u.max())))
+    assert u.max() <= 1, (int((u > 1).sum()), float(np.abs(got - exp).max()))
 
 
 def test_identity_warp_exact(A):
@@ -72,7 +73,7 @@ def test_similarity_vs_oracle_and_skimage(A, golden_dir):
     tm = A.canonical_template(68, 256, 256)
     exp = warp_ref.similarity_ref(lm, tm)
     got = A.similarity_device(torch.from_numpy(lm).cuda(), torch.from_numpy(tm).cuda()).cpu().numpy()
-    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(got, exp)         # float64 sums in landmark order on both sides, rounded to float32 once
     assert np.array_equal(got[3], np.array([[1, 0, 0], [0, 1, 0]], np.float32))
     # grid-to-crop scale applied inside the kernel (float64 products, reject marker kept): the same bits as scaling first
     sc = (256.0 / 264.0, 250.0 / 264.0)
@@ -80,7 +81,7 @@ def test_similarity_vs_oracle_and_skimage(A, golden_dir):
     a = A.similarity_device(torch.from_numpy(pre).cuda(), torch.from_numpy(tm).cuda()).cpu().numpy()
     b = A.similarity_device(torch.from_numpy(lm).cuda(), torch.from_numpy(tm).cuda(), sc).cpu().numpy()
     assert np.array_equal(a, b)
-    np.testing.assert_allclose(b, warp_ref.similarity_ref(pre, tm), rtol=1e-6, atol=1e-6)
+    assert np.array_equal(b, warp_ref.similarity_ref(pre, tm))
     for i in range(4):   # scikit-image's Umeyama estimate on its own points
         g = A.similarity_device(torch.from_numpy(gold["src_pts"][i:i + 1]).cuda(),
                                 torch.from_numpy(gold["dst_pts"][i]).cuda()).cpu().numpy()[0]
@@ -91,21 +92,40 @@ def test_warp_vs_skimage_golden(A, golden_dir):
     gold = np.load(os.path.join(golden_dir, "warp_golden.npz"))
     m = torch.from_numpy(gold["mats"][:, :2, :].astype(np.float32)).cuda()
     got = A.warp_device(torch.from_numpy(gold["imgs"]).cuda(), m, 40, 44).cpu().numpy()
-    assert np.abs(got - gold["warped"]).max() < 0.05
+    # skimage maps coordinates in float64, the spec in float32: three fmas on coordinates below 64 px leave at most
+    # ~3 * 2^-24 * 64 = 1.1e-5 px, times a gradient of at most 255 grey levels per px along each axis
+    d = np.abs(got - gold["warped"]).max()
+    print("warp vs scikit-image: max %.3g grey levels" % d)
+    assert d < 2 * 255 * 1.2e-5
 
 
 def test_crop_resize_vs_oracle():
+    """uint8 -> uint8 in integer fixed point on both sides (OpenCV's 8-bit INTER_LINEAR restated): bit-exact.  Boxes
+    inside the frame, poking out of every side, outside it, up- and down-scaling, the exact-2x area path."""
     import flm_amd  # noqa: F401
     from flm_amd import prediction
+    from flm_amd.data.generator import resize_u8_device
     rng = np.random.default_rng(14)
     frame = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
-    faces = [[30, 40, 130, 150], [200, 20, 260, 140], [-10, 100, 90, 260], [400, 180, 479, 269]]
+    faces = [[30, 40, 130, 150], [200, 20, 260, 140], [-10, 100, 90, 260], [400, 180, 479, 269], [5, 5, 25, 30]]
     boxes = prediction.face_boxes(faces)
     assert boxes == [warp_ref.square_box_ref(f) for f in faces]
-    got = prediction.crop_faces_device(torch.from_numpy(frame).cuda(), boxes, 64, 64).cpu().numpy()
-    exp = warp_ref.crop_resize_ref(frame, np.asarray(boxes), 64, 64)
-    d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    boxes = boxes + [[100, 60, 228, 188], [-40, -40, 30, 30], [450, 240, 520, 310], [600, 10, 700, 110], [0, 0, 480, 270]]
+    fd = torch.from_numpy(frame).cuda()
+    for oh, ow in ((64, 64), (128, 96), (33, 47)):
+        got = prediction.crop_faces_device(fd, boxes, oh, ow).cpu().numpy()
+        exp = warp_ref.crop_resize_ref(frame, np.asarray(boxes), oh, ow)
+        assert np.array_equal(got, exp), (oh, ow, int((got != exp).sum()))
+    assert not got[8].any()                       # box beyond the frame: zeros
+    # [100,60,228,188] -> 64x64 is the exact 2x downscale: cv2 averages 2x2 blocks there
+    blk = frame[60:188, 100:228].astype(np.int32)
+    area = (blk[0::2, 0::2] + blk[0::2, 1::2] + blk[1::2, 0::2] + blk[1::2, 1::2] + 2) >> 2
+    got = prediction.crop_faces_device(fd, boxes, 64, 64).cpu().numpy()
+    assert np.array_equal(got[5], area.astype(np.uint8))
+    # whole-image resize of get_image_array (data/generator.py:53)
+    for oh, ow in ((256, 256), (135, 240), (540, 960)):
+        got = resize_u8_device(fd, oh, ow).cpu().numpy()
+        assert np.array_equal(got, warp_ref.resize_u8_ref(frame, oh, ow)), (oh, ow)
 
 
 def test_get_image_array_device_matches_reference_semantics():

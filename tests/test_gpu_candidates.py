@@ -24,21 +24,10 @@ def weights68():
     return synth_fcn8_weights(68, seed=2)
 
 
-def _knob(key, value):
-    from flm_amd import _lib
-    _lib.check(_lib.load().flm_set_tuning(key, value), "set_tuning")
-
-
 def _landmarks(model, xd, n_points, thresh, candidates, cap_div=1):
-    _knob(b"landmark_candidates", 1 if candidates else 0)
-    _knob(b"candidate_cap_div", cap_div)
-    model._ws.clear()  # the workspace layout depends on the knobs
-    try:
-        return model.forward_device(xd, "landmarks", n_points=n_points, thresh=thresh).cpu().numpy()
-    finally:
-        _knob(b"landmark_candidates", 1)
-        _knob(b"candidate_cap_div", 1)
-        model._ws.clear()
+    """The options that pick the path are per-call arguments (flm_forward_opts), so each layout has its own workspace."""
+    opts = dict(landmark_candidates=1 if candidates else 0, candidate_cap_div=cap_div)
+    return model.forward_device(xd, "landmarks", n_points=n_points, thresh=thresh, opts=opts).cpu().numpy()
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -135,10 +124,9 @@ def test_candidate_path_does_not_need_its_fallback_on_ordinary_maps(flm, weights
     model.load_weights(weights68)
     xd = torch.from_numpy(np.random.default_rng(46).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
     for n_points in (4, 25):
-        model._ws.clear()
-        model.forward_device(xd, "landmarks", n_points=n_points)
+        ws = model.new_workspace(n, "landmarks", n_points)
+        model.forward_device(xd, "landmarks", n_points=n_points, workspace=ws)
         torch.cuda.synchronize()
-        ws = model._workspace(n, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN, n_points)
 
         def off(name):
             return lib.flm_fcn8_workspace_offset(name, n, 256, 256, 68, model._dt, _lib.OUT_LANDMARKS,

@@ -49,6 +49,7 @@ def test_golden_get_average_xy(M, gold):
 def test_golden_transfer_target_as_shipped(M, gold):
     y = gold["tt_input"]
     assert np.array_equal(M.transfer_target(y, as_shipped=True), gold["tt_shipped_default"])
+    assert np.array_equal(M.transfer_target(y), gold["tt_shipped_default"])   # the default call IS the reference's
     assert np.array_equal(M.transfer_target(y, 0.2, 25, as_shipped=True), gold["tt_shipped_args"])
     # honouring the documented arguments instead (n=4, thresh=0 asked explicitly) gives the same
     assert np.array_equal(M.transfer_target(y, 0, 4), gold["tt_shipped_default"])

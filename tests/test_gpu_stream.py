@@ -32,12 +32,10 @@ def test_detect_marks_batch_1080p(setup):
     fd = torch.from_numpy(frame).cuda()
     crops = prediction.crop_faces_device(fd, boxes, 256, 256)
     exp_crops = warp_ref.crop_resize_ref(frame, np.asarray(boxes), 256, 256)
-    d = np.abs(crops.cpu().numpy().astype(np.int32) - exp_crops.astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert np.array_equal(crops.cpu().numpy(), exp_crops)      # integer fixed point on both sides
     marks = prediction.detect_marks_batch(frame, model, faces, n_points=0)
     assert marks.shape == (3, 68, 2) and marks.dtype == np.uint
-    # oracle on the SAME crops (the crop's rare 1-LSB rounding differences would otherwise move the input)
-    cg = crops.cpu().numpy()
+    cg = exp_crops
     x = np.stack([fcn_ref.get_image_array_ref(c) for c in cg])
     pr = fcn_ref.fcn8_predict_ref(x, params).reshape(3, 264, 264, 68)
     with np.errstate(all="ignore"):
@@ -90,6 +88,81 @@ def test_keypts_predict_returns_class_map(setup, tmp_path):
     assert diff.mean() < 1e-3
     import os
     assert os.path.getsize(out) > 0
+
+
+def test_checkpoint_files_are_found_loaded_and_run(setup, tmp_path):
+    """what the trainer leaves on disk (training.py:187-200: `<ckpt>.<epoch>` weight files and a
+    `<ckpt>_config.json` WITHOUT input_height/input_width) -> `keypts_predict(checkpoints_path=...)`
+    (prediction.py:116-133,166-170) -> class map on the device.  The newest epoch must be the one that runs."""
+    import json
+    from flm_amd.weights import save_weights, synth_fcn8_weights
+    prediction, _, params = setup
+    ckpt = str(tmp_path / "fcn8_run")
+    old = synth_fcn8_weights(68, seed=99)
+    save_weights(ckpt + ".00003.npz", old)            # an older epoch with other weights
+    save_weights(ckpt + ".00012.npz", params)         # the newest by NUMERIC suffix (12 > 3; a string sort would agree,
+    save_weights(ckpt + ".00007.npz", old)            #  a directory-order pick would not)
+    with open(ckpt + "_config.json", "w") as f:       # training.py:195-200: no input dims
+        json.dump({"model_class": "fcn_8", "n_classes": 68, "output_height": 264, "output_width": 264}, f)
+    assert prediction.find_latest_checkpoint(ckpt).endswith(".00012.npz")
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    cm = prediction.keypts_predict(inp=img, checkpoints_path=ckpt)
+    assert cm.shape == (264, 264) and cm.dtype == np.int64
+    ref_cm, pr = fcn_ref.prediction_ref(img, params, 68)
+    diff = cm != ref_cm
+    if diff.any():
+        srt = np.sort(pr.reshape(264, 264, 68), axis=-1)
+        assert (srt[..., -1] - srt[..., -2])[diff].max() < 2e-6
+    assert diff.mean() < 1e-3
+    old_cm, _ = fcn_ref.prediction_ref(img, old, 68)
+    assert (cm != old_cm).mean() > 0.5               # not the stale epoch's weights
+    model = prediction.model_from_checkpoint_path(ckpt)
+    assert (model.input_height, model.input_width, model.n_classes, model.model_name) == (256, 256, 68, "fcn_8")
+    # an image that is not at model size goes through the resize of get_image_array (generator.py:53) first
+    big = rng.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    cm2 = prediction.keypts_predict(model=model, inp=big)
+    small = warp_ref.resize_u8_ref(big, 256, 256)
+    ref2, pr2 = fcn_ref.prediction_ref(small, params, 68)
+    d2 = cm2 != ref2
+    if d2.any():
+        srt = np.sort(pr2.reshape(264, 264, 68), axis=-1)
+        assert (srt[..., -1] - srt[..., -2])[d2].max() < 2e-6
+    with pytest.raises(AssertionError):
+        prediction.model_from_checkpoint_path(str(tmp_path / "nothing_here"))
+
+
+def test_video_predict_frame_loop(setup):
+    """prediction.py:99-113 with the camera and the window replaced by arguments: every frame's faces in one batch,
+    marks drawn into the frame, frames without faces pass through, the sink's False ends the loop ('q')."""
+    prediction, model, _ = setup
+    rng = np.random.default_rng(78)
+    frames = [rng.integers(0, 200, (480, 640, 3), dtype=np.uint8) for _ in range(4)]
+    rects = [[[100, 100, 260, 300], [350, 120, 500, 330]], [], [[200, 150, 400, 420]], [[10, 10, 100, 100]]]
+    seen = []
+
+    def detector(img):
+        return rects[len(seen)]
+
+    def sink(img, marks):
+        seen.append((img.copy(), marks))
+        return len(seen) < 3          # stop after the third frame
+
+    originals = [f.copy() for f in frames]
+    n = prediction.video_predict(detector, model, frames=frames, on_frame=sink)
+    assert n == 3 and len(seen) == 3
+    assert seen[0][1].shape == (2, 68, 2) and seen[1][1].shape == (0, 68, 2) and seen[2][1].shape == (1, 68, 2)
+    assert np.array_equal(frames[1], originals[1]) and np.array_equal(frames[3], originals[3])   # no faces / not reached
+    for k in (0, 2):
+        exp = prediction.detect_marks_batch(originals[k], model, rects[k])
+        assert np.array_equal(seen[k][1], exp)
+        x, y = int(exp[0, 0, 0]), int(exp[0, 0, 1])
+        if 2 <= x < 638 and 2 <= y < 478:
+            assert frames[k][y, x].tolist() == [0, 255, 0]        # draw_marks' default colour at the first landmark
+        assert (frames[k] != originals[k]).any()
+    assert prediction.detect_marks_batch(frames[0], model, []).shape == (0, 68, 2)
+    with pytest.raises(ValueError):
+        prediction.video_predict(detector, model)
 
 
 def test_empty_and_ragged_batches(setup):
@@ -150,6 +223,29 @@ def test_captured_pipeline_equals_eager_sequence(setup):
             assert torch.equal(lm, lm_e) and torch.equal(m, m_e) and torch.equal(aligned, al_e), (n, rep)
         with pytest.raises(ValueError):
             pipe(torch.zeros((n + 1, 256, 256, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_captured_pipelines_survive_workspace_cache_eviction(setup):
+    """One pipe per face count on ONE model (the stream caller's use: 1-16 faces per frame) plus eager calls at other
+    batch sizes push the model's workspace cache through several evictions; every graph owns its workspace, so the first
+    pipe still replays onto live memory and equals the eager result."""
+    from flm_amd import alignment, graphs
+    _, model, _ = setup
+    rng = np.random.default_rng(62)
+    crops = torch.from_numpy(rng.integers(0, 256, (8, 256, 256, 3), dtype=np.uint8)).cuda()
+    pipes = {n: graphs.CapturedPipeline(model, n, n_points=4) for n in (1, 2, 3, 4, 5, 6, 7)}
+    for n in (8, 3, 6, 1, 5, 2, 7):                      # eager batch sizes: more keys than the cache holds
+        model.forward_device(crops[:n].contiguous(), "landmarks", n_points=4)
+        model.forward_device(crops[:n].contiguous(), "classmap")
+    assert len(model._ws) <= model._ws_cap
+    filler = [torch.full((1 << 22,), 0xAB, dtype=torch.uint8, device="cuda") for _ in range(64)]   # reuse freed blocks
+    for n in (1, 4, 7):
+        x = crops[:n].contiguous()
+        lm, aligned, m = [t.clone() for t in pipes[n](x)]
+        lm_e = model.forward_device(x, "landmarks", n_points=4)
+        al_e, m_e = alignment.align_device(x, lm_e, pipes[n].template, 256, 256, pipes[n].scale)
+        assert torch.equal(lm, lm_e) and torch.equal(m, m_e) and torch.equal(aligned, al_e), n
+    assert all(int(f[0]) == 0xAB and int(f[-1]) == 0xAB for f in filler)     # nothing scribbled over other tensors
 
 
 def test_bf16_faces_do_not_depend_on_their_batch(setup):

@@ -34,6 +34,46 @@ def test_warp_matches_skimage(gold):
     assert np.abs(got - gold["warped"]).max() < 0.05
 
 
+def test_fma_is_correctly_rounded():
+    """oracle fma == the hardware's: a crafted double-rounding case (float64 sum lands exactly on a float32 rounding
+    boundary with the lost bits below it) and random operands against exact rational arithmetic."""
+    from fractions import Fraction
+    a, b, c = np.float32(2 ** 15 + 2 ** -8), np.float32(2 ** 15 - 2 ** -8), np.float32(2 ** 54 + 2 ** 31)
+    naive = np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+    assert float(naive) == 2.0 ** 54 + 2.0 ** 32                       # what rounding twice gives
+    assert float(warp_ref.fma(a, b, c)) == 2.0 ** 54 + 2.0 ** 31       # a*b + c = 2^54 + 2^31 + 2^30 - 2^-16
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(400).astype(np.float32)
+    b = rng.standard_normal(400).astype(np.float32)
+    c = (-(a.astype(np.float64) * b) + rng.standard_normal(400) * 1e-4).astype(np.float32)   # heavy cancellation
+    r = warp_ref.fma(a, b, c)
+    for i in range(400):
+        ex = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        near = np.float32(float(ex))
+        cands = (np.nextafter(near, np.float32(-np.inf)), near, np.nextafter(near, np.float32(np.inf)))
+        best = min(cands, key=lambda v: (abs(Fraction(float(v)) - ex), int(np.float32(v).view(np.uint32)) & 1))
+        assert r[i] == best
+
+
+def test_resize_u8_fixed_point_properties():
+    """oracle/warp_ref.resize_u8_ref (OpenCV's 8-bit INTER_LINEAR restated; cv2 is absent, so parity with the library
+    itself is unpinned): identity at equal size, constants stay constant, the 2x area path, hand-worked weights."""
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (30, 44, 3), dtype=np.uint8)
+    assert np.array_equal(warp_ref.resize_u8_ref(img, 30, 44), img)
+    flat = np.full((17, 23, 3), 201, np.uint8)
+    assert (warp_ref.resize_u8_ref(flat, 40, 9) == 201).all()
+    blk = img.astype(np.int32)
+    area = (blk[0::2, 0::2] + blk[0::2, 1::2] + blk[1::2, 0::2] + blk[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(warp_ref.resize_u8_ref(img, 15, 22), area.astype(np.uint8))
+    # 2 -> 4 upscale of a row [0, 200]: f = (d+.5)/2 - .5 = -.25, .25, .75, 1.25 -> weights 2048|0, 1536|512, 512|1536, 2048|0
+    row = np.array([[[0], [200]]], np.uint8)
+    out = warp_ref.resize_u8_ref(row, 1, 4)[0, :, 0]
+    assert out.tolist() == [0, 50, 150, 200]
+    s0, s1, w0, w1 = warp_ref._resize_coef(4, 2)
+    assert s0.tolist() == [0, 0, 0, 1] and w1.tolist() == [0, 512, 1536, 0] and (w0 + w1 == 2048).all()
+
+
 def test_similarity_skips_rejected_landmarks():
     rng = np.random.default_rng(0)
     p = rng.uniform(10, 200, (1, 10, 2))

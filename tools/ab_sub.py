@@ -1,4 +1,4 @@
-"""Developer tool: sampling-launch phases per tile (flm_set_tuning "candidate_sub_phases") vs time, list fill and the
+"""Developer tool: sampling-launch phases per tile (flm_forward_opts.candidate_sub_phases) vs time, list fill and the
 fallback flag, headline batch (fp32, 64) and bf16 batch 512."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,21 +16,21 @@ for dtype, B in (("f32", 64), ("bf16", 512)):
     x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
     for npts in [int(v) for v in os.environ.get("NPTS", "4,25").split(",")]:
         for sub in [int(v) for v in os.environ.get("SUBS", "4,3,2,1").split(",")]:
-            _lib.check(lib.flm_set_tuning(b"candidate_sub_phases", sub), "set_tuning")
-            model._ws.clear()
+            opts = dict(candidate_sub_phases=sub)
+            ws = model.new_workspace(B, "landmarks", npts, opts)
             for _ in range(3):
-                model.forward_device(x, "landmarks", n_points=npts)
+                model.forward_device(x, "landmarks", n_points=npts, workspace=ws, opts=opts)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
-                model.forward_device(x, "landmarks", n_points=npts)
+                model.forward_device(x, "landmarks", n_points=npts, workspace=ws, opts=opts)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 10
-            ws = model._workspace(B, _lib.OUT_LANDMARKS, _lib.DECODE_TOPN, npts)
-            off = lambda name: lib.flm_fcn8_workspace_offset(name, B, 256, 256, 68, model._dt, _lib.OUT_LANDMARKS,
-                                                             _lib.DECODE_TOPN, npts)
+            fo = model._opts(opts)
+            import ctypes as C
+            off = lambda name: lib.flm_fcn8_workspace_offset_opts(name, B, 256, 256, 68, model._dt, _lib.OUT_LANDMARKS,
+                                                                  _lib.DECODE_TOPN, npts, C.byref(fo))
             cap = off(b"cand_cap")
             cnt = ws[off(b"cand_cnt"):off(b"cand_cnt") + 4 * (B + 1)].view(torch.int32).cpu().numpy()
             print("%s n_points %2d sub %d: %.3f ms  keys/face min %d max %d (cap %d)  fallback %d" %
                   (dtype, npts, sub, 1e3 * dt, cnt[:B].min(), cnt[:B].max(), cap, cnt[B]), flush=True)
-_lib.check(lib.flm_set_tuning(b"candidate_sub_phases", 0), "set_tuning")

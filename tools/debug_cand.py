@@ -12,9 +12,9 @@ B = int(os.environ.get("B", "4")); NP = int(os.environ.get("NP", "4"))
 model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=os.environ.get("DTYPE", "f32"))
 model.load_weights(synth_fcn8_weights(68, 2))
 x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
-lm = model.forward_device(x, "landmarks", n_points=NP)
+ws = model.new_workspace(B, "landmarks", NP)
+lm = model.forward_device(x, "landmarks", n_points=NP, workspace=ws)
 torch.cuda.synchronize()
-ws = model._workspace(B, _lib.OUT_LANDMARKS, 1, NP)
 def off(name):
     return lib.flm_fcn8_workspace_offset(name.encode(), B, 256, 256, 68, model._dt, _lib.OUT_LANDMARKS, 1, NP)
 cap = off("cand_cap")

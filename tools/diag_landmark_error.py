@@ -33,6 +33,22 @@ def main():
     lg_hip = model.forward_device(xd, "logits").cpu().numpy().reshape(n, -1, c)
     pr_hip = model.forward_device(xd, "probs").cpu().numpy().reshape(n, -1, c)
     x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in crops])
+    names = ("f1", "f2", "f3", "f4", "f5", "fc6", "fc7", "fuse4", "seg_feats")
+    inter_hip = {k: model.intermediate(k, n, "probs").cpu().numpy() for k in names}
+    _, i64 = fcn_ref.fcn8_logits_ref(x_ref[:2], w, torch.float64, return_intermediates=True)
+    _, i32 = fcn_ref.fcn8_logits_ref(x_ref[:2], w, torch.float32, return_intermediates=True)
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    print("relative RMS error against the float64 oracle, layer by layer (first two faces):")
+    for k in names:
+        h = inter_hip[k][:2][..., : i64[k].shape[-1]].astype(np.float64)
+        print("  %-9s hip %.3g   float32 oracle %.3g" % (k, rms(h, i64[k]), rms(i32[k].astype(np.float64), i64[k])))
+    # up3 alone: exact (float64) transposed conv of the HIP path's own seg_feats against the HIP logits
+    seg = torch.from_numpy(inter_hip["seg_feats"][:2][..., :c].astype(np.float64)).permute(0, 3, 1, 2)
+    lg_from_seg = fcn_ref._convT(seg, w["up3/kernel"], 8, torch.float64).permute(0, 2, 3, 1).reshape(2, -1, c).numpy()
+    l64 = fcn_ref.fcn8_logits_ref(x_ref[:2], w, torch.float64).reshape(2, -1, c)
+    print("logits: rms |hip - exact up3 of hip seg_feats| %.3g (up3's own rounding), rms |exact up3 of hip seg_feats - o64| %.3g "
+          "(everything before it), rms |hip - o64| %.3g" % (np.sqrt(np.mean((lg_hip[:2] - lg_from_seg) ** 2)),
+          np.sqrt(np.mean((lg_from_seg - l64) ** 2)), np.sqrt(np.mean((lg_hip[:2] - l64) ** 2))))
     for npts in (4, 25):
         ea, eb, ec, sm = [], [], [], []
         for i in range(n):

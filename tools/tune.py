@@ -35,7 +35,6 @@ key = sys.argv[1]
 vals = [int(v) for v in sys.argv[2].split(",")]
 for v in vals:
     _lib.check(lib.flm_set_tuning(key.encode(), v), "set_tuning")
-    model._ws.clear()  # some knobs change the workspace layout
     r = run()
     keys = list(r.keys())
     print("%-8s" % key[:8], " ".join("%7s" % k[:7] for k in keys), "   total")
