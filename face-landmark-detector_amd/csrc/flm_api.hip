@@ -233,6 +233,18 @@ int flm_set_tuning(const char* key, int value) {
               "flm_fcn_workspace_bytes_opts / flm_fcn_forward_opts", key);
     return FLM_ERR_ARG;
   }
+  if (!strcmp(key, "bf16_cand8")) {  // bf16 candidate launch of up3: 1 the 8-wave kernel (default), 0 the generic one
+    flm::convt_cand8_enable(value);
+    return FLM_OK;
+  }
+  if (!strcmp(key, "bf16_cand8_rows")) {  // phase rows per workgroup of that kernel: 0 automatic, else 1, 2, 4 or 8
+    if (value < 0 || value > 32 || (value & (value - 1))) {
+      set_error("flm_set_tuning: bf16_cand8_rows must be 0 or a power of two <= 32");
+      return FLM_ERR_ARG;
+    }
+    flm::convt_cand8_rows(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_conv3_halo")) {  // halo-resident 3x3 kernel for 64-channel inputs: 0 off, 1 auto, 2 always
     flm::conv3_halo_enable(value);
     return FLM_OK;

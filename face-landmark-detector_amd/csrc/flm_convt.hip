@@ -38,6 +38,8 @@
 //      the decode of the materialised map.
 // A list that overflows (flat maps: everything ties with tau) raises a flag; the materialising launch and
 // the ordinary decode follow in the stream, gated on that flag, so the result is exact in every case.
+#include <utility>
+
 #include "flm_common.h"
 
 namespace flm {
@@ -66,6 +68,7 @@ struct ConvTArgs {
   unsigned* cand_cnt;         // [n] entries appended per face; cand_cnt[n] = overflow flag
   int cand_cap;
   const unsigned* gate;       // non-null: the launch does nothing unless *gate != 0
+  int rpw;                    // cand8 kernel: phase rows a0 one workgroup walks with the same X fragments (divides s)
 };
 
 // candidate keys one wave can hold in LDS: 128 (fp32) or 256 (bf16, NT = 2) pixels x 68 classes pass through it;
@@ -78,6 +81,13 @@ __device__ __forceinline__ unsigned cand_order_bits(float v) {
   return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
 
+// Developer ablations (tools/ablate_up3.py builds variants with -DFLM_ABLATE=<mask>; results are wrong, only timings
+// mean anything): 1 no candidate test / stores (part 3), 2 no normalisation (part 2), 4 no max / exp (part 1),
+// 8 no MFMAs, 16 no weight ring (loads, LDS stores, barriers); cand8 kernel: 32 prologue only, 64 no end-of-phase
+// wait + barrier, 128 no hit loop, 256 no softmax / threshold ops, 512 no MFMAs, 1024 no LDS-DMA.  0 in every shipped build.
+#ifndef FLM_ABLATE
+#define FLM_ABLATE 0
+#endif
 constexpr int GCH_F32 = 6, GCH_BF16 = 3;  // k groups per LDS chunk (bf16: smaller chunks, fewer staging registers)
 
 // exp(t) for t <= 0 in the softmax.  fp32 path: the accurate library expf.  bf16 path: v_exp_f32 on
@@ -173,8 +183,9 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
     for (int c = lane; c < a.sub * 16 * MT; c += 64) wmax[c] = 0u;
 
   const int s = a.s;
-  // Phase (a0, b0) of iteration IT of this workgroup: phase row blockIdx.y, b0 = IT; in the sampling launch the
-  // IT-th entry of the tile's list -- an odd stride walks all s*s phases before repeating.
+  // Phase (a0, b0) of iteration IT of this workgroup: packed phase blockIdx.y * nb + IT (nb = s for one phase row per
+  // workgroup; a multiple of s when the workgroup walks several rows with the same X fragments, see convt_rows_per_wg);
+  // in the sampling launch the IT-th entry of the tile's list -- an odd stride walks all s*s phases before repeating.
   const int tile_pf = a.sub ? (int)(blockIdx.x % (a.ppf / (64 * NT))) : 0;
   // Shared tile-4 layout (template SHARE, packed weights per convt_share_layout): the four extra classes 64..67 of FOUR consecutive phases b0 = 4gb .. 4gb+3 are
   // rows 4q + j of the leader phase's tile 4 (X is the same for every phase, only the filter differs), so the short
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   // holds their own classes 64..67 (rows 4q): the sampling launch multiplies all five tiles of whatever phase it draws,
   // so its probabilities are the main launch's bit for bit.
 #define FLM_PHASE(IT)                                                                                    \
-  (a.sub ? (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)) : ((int)blockIdx.y * s + (IT)))
+  (a.sub ? (((tile_pf * a.sub + (IT)) * 23 + 5) & (s * s - 1)) : ((int)blockIdx.y * a.nb + (IT)))
 
 
   // ---- this lane's NT input positions (NT pixel tiles of 16 per wave: the phase's weights, streamed once
@@ -474,17 +485,17 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                            \
-      const bool more = seq + 1 < total;                                                            \
+      const bool more = seq + 1 < total && !(FLM_ABLATE & 16);                                      \
       if (more) FLM_ISSUE(seq + 1)                                                                  \
       const float4* wl = lds + (seq & 1) * CHUNK_F4;                                                \
       if (b0 > 0) {                                                                                 \
-        if (ch == 0) FLM_EPI_PART1(PV)                                                              \
-        if (ch == (NCH > 1 ? 1 : 0)) FLM_EPI_PART2(PV, b0 - 1)                                      \
-        if (ch == NCH - 1) FLM_EPI_PART3(PV, b0 - 1)                                                \
+        if (ch == 0 && !(FLM_ABLATE & 4)) FLM_EPI_PART1(PV)                                         \
+        if (ch == (NCH > 1 ? 1 : 0) && !(FLM_ABLATE & 2)) FLM_EPI_PART2(PV, b0 - 1)                 \
+        if (ch == NCH - 1 && !(FLM_ABLATE & 1)) FLM_EPI_PART3(PV, b0 - 1)                           \
       }                                                                                             \
       _Pragma("unroll") for (int gl = 0; gl < GCH; ++gl) {                                          \
         const int g = ch * GCH + gl; /* compile-time */                                             \
-        if (g < G) {                                                                                \
+        if (g < G && !(FLM_ABLATE & 8)) {                                                           \
           float4 af[MT];                                                                            \
           _Pragma("unroll") for (int m = 0; m < (MTP); ++m) af[m] = wl[(gl * MT + m) * 64 + lane];  \
           if constexpr (BF) {                                                                       \
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
         }                                                                                           \
       }                                                                                             \
       if (more) FLM_STASH((seq + 1) & 1)                                                            \
-      __syncthreads();                                                                              \
+      if (!(FLM_ABLATE & 16)) __syncthreads();                                                      \
       ++seq;                                                                                        \
     }                                                                                               \
   }
@@ -594,6 +605,424 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
 #undef FLM_LD1
 #undef FLM_ST1
 
+
+// Phase rows per workgroup.  A workgroup's X fragments (one burst of global loads that every CU issues at once, plus the
+// index arithmetic behind it) serve rows * s phases: more rows amortise that prologue, fewer keep the last round of
+// workgroups full.  Picks the cheaper by rounds x (prologue + phases), the prologue priced at kProlog phases (bf16 batch
+// 512, 8-wave kernel: 2.75 ms with one row per workgroup, 2.40 / 2.18 / 2.15 with 2 / 4 / 8).  `forced` > 0 overrides.
+static int convt_rows_per_wg(int xblocks, int s, int wg_slots, int forced = 0) {
+  constexpr double kProlog = 2.5;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int rows = 1; rows <= s; rows *= 2) {
+    if (forced == rows) return rows;
+    const long long wgs = (long long)xblocks * (s / rows);
+    const double cost = (double)((wgs + wg_slots - 1) / wg_slots) * (kProlog + (double)rows * s);
+    if (cost < best_cost) {
+      best = rows;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+// =====================================================================================================================
+// up3 in landmark mode (epilogue 3) for the bf16 68-class model: a kernel of its own (`cand8`).
+//
+// What the generic kernel above spends its time on in this mode (tools/ablate_up3.py, batch 512: 2.63 ms): the weight
+// ring alone -- global -> registers -> ds_write -> barrier, three chunks per phase, 13.6 GB per launch out of L2 -- takes
+// 1.40 ms with everything else compiled out; the ten threshold reads per phase each expose an LDS round trip; the
+// candidate code, inlined at 160 sites, pushes the loop past the instruction cache (68 KB).  Here:
+//   * 8 waves per workgroup, one workgroup per CU: the phase's weights are fetched once per 256 positions (half the
+//     bytes), straight into LDS by LDS-DMA (no staging registers, no ds_write pass), in whole-phase slots -- ONE
+//     barrier per phase instead of three; the fifth class tile of the three short phases of a group is not fetched;
+//   * per-face padding at wave granularity (32 positions: 1089 -> 1120 instead of 1152 per face); a wave's thresholds
+//     live in 20 registers (the staging registers' room), its face may differ from its neighbours';
+//   * the softmax / threshold test of phase b-1 is cut into 134 small ops dealt over the 72 MFMA slots of phase b by
+//     cost (compile-time schedule, order pinned with sched_barrier): both waves of a SIMD run the same even mix of
+//     matrix and vector work, so they need not drift apart to overlap;
+//   * hits (about one value in 500) only set a bit per (pixel tile, class tile) group; ONE shared loop per phase then
+//     re-tests the flagged groups and appends the keys -- the code that was inlined 160 times exists twice.
+// Arithmetic per value is the generic kernel's, operation by operation (same MFMA order over k, same max / exp2 / sum
+// order / rcp / product), so keys carry the very bits its materialising and sampling launches produce: thresholds taken
+// from the sampling launch stay valid, and the landmark result is bit-identical (tests/test_gpu_candidates.py).
+// =====================================================================================================================
+namespace cand8 {
+constexpr int MT = 5, G = 9, NT = 2, WAVES = 8;
+constexpr int PIECE = 1024;                 // one (g, m) fragment tile: 64 lanes x 16 bytes
+constexpr int SLOT_BYTES = G * MT * PIECE;  // 46,080 bytes: the weights of a whole phase
+constexpr int KEY_CAP = 512;                // keys a wave holds in LDS between flushes
+constexpr int NSLOT = G * 4 * NT;           // 72 MFMAs of the four common class tiles per phase and wave
+constexpr size_t LDS_BYTES = 2 * (size_t)SLOT_BYTES + (size_t)WAVES * KEY_CAP * 8;
+
+// ---- the epilogue of one phase as a list of small ops (both pixel tiles interleaved: op k works on nt = k & 1) -------
+//   A  18  running class maximum, two values per v_max3        B  2  cross-lane-group maximum, -max*log2(e)
+//   C  34  e = exp2(fma(x, log2(e), -max*log2(e)))              D  34  sum += e (the generic kernel's order)
+//   E   2  cross-lane-group sum, reciprocal, pixel validity     F  34  p = e * (1/sum)
+//   G  10  p >= tau for the 4 (1) values of a class tile -> one bit per group          (A starts at op 0)
+constexpr int B0 = 18, C0 = 20, D0 = 54, E0 = 88, F0 = 90, G0 = 124, NOPS = 134;
+constexpr int op_cost(int k) {  // issue cycles / 4, roughly (v_exp_f32 8, the rest 4)
+  return k < B0 ? 1 : k < C0 ? 7 : k < D0 ? 3 : k < E0 ? 1 : k < F0 ? 8 : k < G0 ? 1 : 5;
+}
+struct EpiSched {
+  int first[NSLOT + 1];  // ops [first[s], first[s+1]) run beside MFMA slot s
+  constexpr EpiSched() : first() {
+    int total = 0;
+    for (int k = 0; k < NOPS; ++k) total += op_cost(k);
+    int k = 0, cum = 0;
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      first[sl] = k;
+      // slot sl takes ops while the cumulated cost stays within its share (the last slots end a little early: the
+      // shared hit loop follows them)
+      while (k < NOPS && (cum + op_cost(k)) * (long long)NSLOT <= (long long)total * (sl + 1)) cum += op_cost(k++);
+    }
+    first[NSLOT] = NOPS;
+  }
+};
+constexpr EpiSched kSched{};
+static_assert(kSched.first[NSLOT - 1] <= NOPS, "schedule");
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// LDS-DMA: buffer_load_dwordx4 ... lds writes lane l's 16 bytes to LDS address M0 + 16*l, no VGPR destination.  Inline
+// assembly: through the builtin hipcc would order every later ds_read behind the pending request (vmcnt(0)).
+typedef int dma_srd __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_piece(dma_srd srd, unsigned lds_addr, unsigned voffset, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voffset), "s"(srd), "s"(soffset)
+               : "memory");
+}
+}  // namespace cand8
+
+__global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  // 8 waves = 2 per SIMD: 256 registers each
+  using namespace cand8;
+  if (a.gate && *a.gate == 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned ring_lds = (unsigned)(size_t)((lds_char*)smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  unsigned long long* cwave = reinterpret_cast<unsigned long long*>(smem_raw + 2 * SLOT_BYTES) + wave * KEY_CAP;
+  unsigned wcnt = 0;
+
+  const int s = a.s;
+  const int row0 = blockIdx.y * a.rpw;   // this workgroup walks phase rows row0 .. row0 + rpw - 1, phases t = 0 .. rpw*s - 1
+  const int nph = a.rpw * s;
+  const int ls = a.ls;
+  // ---- this wave's 32 positions: one face (ppf is a multiple of 32) ------------------------------------------------
+  const int wi1 = a.wi + 1, hi1 = a.hi + 1;
+  const int p0 = (blockIdx.x * WAVES + wave) * 16 * NT;
+  const int wimg = p0 / a.ppf;
+  const bool wlive = wimg < a.n;
+  bool pvalid[NT];
+  int oy0[NT], ox0[NT];   // output pixel of phase (a0, b0): (oy0 + a0, ox0 + b0)
+  int i0[NT], j0[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int pl = p0 % a.ppf + nt * 16 + r;
+    pvalid[nt] = wlive && pl < wi1 * hi1;
+    const int pp = pvalid[nt] ? pl : 0;
+    j0[nt] = pp % wi1;
+    i0[nt] = pp / wi1;
+    oy0[nt] = s * i0[nt];
+    ox0[nt] = s * j0[nt];
+  }
+  // thresholds of the wave's face, clamped to FLT_MIN so that p >= tau implies p > 0 (a zero weight cannot move a
+  // centroid; a class left with fewer than n keys is caught by cand_merge_kernel), in registers
+  float4 tq[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cls = m < 4 ? 16 * m + 4 * q + e : (e == 0 ? 64 + q : a.C);
+      t[e] = (cls < a.C && wlive) ? fmaxf(a.tau[(size_t)wimg * a.C + cls], 1.17549435e-38f) : 3.402823466e38f;
+    }
+    tq[m] = make_float4(t[0], t[1], t[2], t[3]);
+  }
+
+  // ---- X fragments: xf[nt][g] = bf16(x[tap(k8)][c(k8)..+7]), k8 = 32g + 8q, as the generic kernel -------------------
+  float4 xf[NT][G];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 32 * g + 8 * q;
+      const int tap = k0 / a.Cp, c = k0 % a.Cp;
+      const int ii = i0[nt] - (tap >> 1), jj = j0[nt] - (tap & 1);
+      const bool ok = wlive && tap < 4 && (unsigned)ii < (unsigned)a.hi && (unsigned)jj < (unsigned)a.wi &&
+                      (p0 % a.ppf + nt * 16 + r) < wi1 * hi1;
+      const size_t off = ok ? (((size_t)wimg * a.hi + ii) * a.wi + jj) * a.Cp + c : 0;
+      const float4 v0 = *reinterpret_cast<const float4*>(a.x + off);
+      const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
+      bf16x8 t;
+      t[0] = (__bf16)(ok ? v0.x : 0.f); t[1] = (__bf16)(ok ? v0.y : 0.f);
+      t[2] = (__bf16)(ok ? v0.z : 0.f); t[3] = (__bf16)(ok ? v0.w : 0.f);
+      t[4] = (__bf16)(ok ? v1.x : 0.f); t[5] = (__bf16)(ok ? v1.y : 0.f);
+      t[6] = (__bf16)(ok ? v1.z : 0.f); t[7] = (__bf16)(ok ? v1.w : 0.f);
+      xf[nt][g] = __builtin_bit_cast(float4, t);
+    }
+
+  // ---- weight ring: two whole-phase slots filled by LDS-DMA; wave w moves pieces w, w+8, ... of the next phase --------
+  const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wf);
+  const dma_srd wsrd = (dma_srd){(int)(unsigned)wbase, (int)(unsigned)((wbase >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+  const unsigned voff = (unsigned)lane * 16u;
+  // piece i of the workgroup's phase t = b -> (g, m): a leader phase (t % 4 == 0) has 45 pieces, a short one the 36 of
+  // tiles 0..3; the packed phases of consecutive rows are consecutive, so phase t is packed phase row0*s + t
+  auto dma_issue = [&](int b, int i) __attribute__((always_inline)) {
+    const bool leader = (b & 3) == 0;
+    const int np = leader ? G * MT : G * 4;
+    if (i < np) {
+      const int pc = leader ? i : (i >> 2) * MT + (i & 3);
+      dma_piece(wsrd, ring_lds + (unsigned)((b & 1) * SLOT_BYTES + pc * PIECE), voff, (row0 * s + b) * SLOT_BYTES + pc * PIECE);
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dma_issue(0, wave + WAVES * k);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
+  __syncthreads();
+
+  f32x4 accA[NT][MT], accB[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) accA[nt][m] = accB[nt][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float x4r[NT][3];  // class 64+q of the three short phases of the current group (rows 4q+1..3 of the leader's fifth tile)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) x4r[nt][0] = x4r[nt][1] = x4r[nt][2] = 0.f;
+
+  // keys of this wave: LDS region -> its face's global list (one atomic reserves the range)
+  auto cand_flush = [&]() __attribute__((always_inline)) {
+    const unsigned found = __builtin_amdgcn_readfirstlane(wcnt);
+    if (wlive && found) {
+      unsigned base = 0;
+      if (lane == 0) {
+        base = atomicAdd(&a.cand_cnt[wimg], found);
+        if (base + found > (unsigned)a.cand_cap) atomicOr(&a.cand_cnt[a.n], 1u);
+      }
+      base = __builtin_amdgcn_readfirstlane(base);
+      for (unsigned i = lane; i < found; i += 64)
+        if (base + i < (unsigned)a.cand_cap) a.cand[(size_t)wimg * a.cand_cap + base + i] = cwave[i];
+    }
+    wcnt = 0;
+  };
+
+  // ---- epilogue state of the phase being finished --------------------------------------------------------------------
+  float mx[NT], nmxl[NT], sum[NT], rs[NT];
+  unsigned hitmask = 0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) mx[nt] = nmxl[nt] = sum[nt] = rs[nt] = 0.f;
+
+  // op K of the list above on the finished phase's values PV; bprev = its b0 (< 0: no phase yet, nothing may hit)
+  // (pin: an empty volatile asm on a value.  The ops are pure arithmetic, which LLVM places wherever the data flow
+  //  allows -- it regrouped the exps and the products into blocks between the MFMAs -- and sched_barrier only fences the
+  //  machine scheduler; a volatile asm keeps its place among the other side-effecting statements, so an op whose RESULT is
+  //  pinned is issued no later than the slot it was written in, and nothing makes hipcc issue it earlier.  Pinning the
+  //  inputs as well cost a hazard s_nop around every pin: 585 in the kernel against 265 this way.)
+#define FLM_PIN(x) asm volatile("" : "+v"(x))
+  auto epi_op = [&](auto kc, f32x4(&PV)[NT][MT], int bprev) __attribute__((always_inline)) {
+    constexpr int K = decltype(kc)::value;
+    if constexpr (K < B0) {
+      constexpr int nt = K & 1, j = K >> 1;
+      if constexpr (j == 0) mx[nt] = max_raw(PV[nt][0][0], PV[nt][0][1]);
+      else if constexpr (j < 8) mx[nt] = max3_raw(mx[nt], PV[nt][j >> 1][2 * (j & 1)], PV[nt][j >> 1][2 * (j & 1) + 1]);
+      else mx[nt] = max_raw(mx[nt], PV[nt][4][0]);
+      FLM_PIN(mx[nt]);
+    } else if constexpr (K < C0) {
+      constexpr int nt = (K - B0) & 1;
+      mx[nt] = reduce_q_max(mx[nt]);
+      nmxl[nt] = -mx[nt] * 1.44269504088896340736f;
+      FLM_PIN(nmxl[nt]);
+    } else if constexpr (K < D0) {
+      constexpr int nt = (K - C0) & 1, i = (K - C0) >> 1, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+      float v = softmax_exp<true>(PV[nt][m][e], mx[nt], nmxl[nt]);
+      FLM_PIN(v);
+      PV[nt][m][e] = v;
+    } else if constexpr (K < E0) {
+      constexpr int nt = (K - D0) & 1, i = (K - D0) >> 1, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+      if constexpr (i == 0) sum[nt] = 0.f + PV[nt][m][e];
+      else sum[nt] += PV[nt][m][e];
+      FLM_PIN(sum[nt]);
+    } else if constexpr (K < F0) {
+      constexpr int nt = (K - E0) & 1;
+      const float sq = reduce_q_sum(sum[nt]);
+      const bool ok = pvalid[nt] && bprev >= 0 && oy0[nt] + row0 + (bprev >> ls) < a.ho && ox0[nt] + (bprev & (s - 1)) < a.wo;
+      rs[nt] = ok ? __builtin_amdgcn_rcpf(sq) : 0.f;
+      FLM_PIN(rs[nt]);
+    } else if constexpr (K < G0) {
+      constexpr int nt = (K - F0) & 1, i = (K - F0) >> 1, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+      float v = PV[nt][m][e] * rs[nt];
+      FLM_PIN(v);
+      PV[nt][m][e] = v;
+    } else {
+      constexpr int nt = (K - G0) & 1, m = (K - G0) >> 1;
+      unsigned long long mk = __ballot(PV[nt][m][0] >= tq[m].x);
+      if constexpr (m < 4) {
+        mk |= __ballot(PV[nt][m][1] >= tq[m].y);
+        mk |= __ballot(PV[nt][m][2] >= tq[m].z);
+        mk |= __ballot(PV[nt][m][3] >= tq[m].w);
+      }
+      hitmask |= mk ? 1u << (nt * MT + m) : 0u;  // (scalar: the products it tests are pinned in their slots)
+    }
+  };
+  // The flagged groups of the finished phase: re-test, append keys (value order bits << 32 | class << 17 | pixel).  Ten
+  // copies of the append code per phase body (one per group, compile-time registers) instead of the generic kernel's
+  // forty, each reached through one wave-uniform bit test and only when some group was flagged.  Kept lean -- per hit
+  // value: the ballot, two mbcnt, the key halves (p > 0, so its order bits are its bits with the sign set; class and
+  // pixel add up from per-lane terms computed once per call), one ds_write_b64.  Room is made once per call (a flush
+  // when the wave's region is half full); a call that still runs out (more than 256 hits of one wave in one phase: flat
+  // maps) drops the excess keys and raises the overflow flag, which sends the batch through the materialising launch.
+  auto hit_loop = [&](f32x4(&PV)[NT][MT], int bprev) __attribute__((always_inline)) {
+    const unsigned hm = __builtin_amdgcn_readfirstlane(hitmask);
+    hitmask = 0;
+    if (hm == 0) return;
+    if (wcnt > (unsigned)(KEY_CAP - 256)) cand_flush();
+    unsigned pixq[NT];  // pixel | (4q << 17): plus (16m + e) << 17 it is class << 17 | pixel for the four common tiles
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      pixq[nt] = (unsigned)((oy0[nt] + row0 + (bprev >> ls)) * a.wo + ox0[nt] + (bprev & (s - 1))) + ((unsigned)(4 * q) << 17);
+    static_for<NT * MT>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int grp = decltype(gc)::value, nt = grp / MT, m = grp % MT;
+      if ((hm >> grp) & 1u) {
+        const float tv[4] = {tq[m].x, tq[m].y, tq[m].z, tq[m].w};
+#pragma unroll
+        for (int e = 0; e < (m < 4 ? 4 : 1); ++e) {
+          const float pvv = PV[nt][m][e];
+          const bool hit = pvv >= tv[e];
+          const unsigned long long mk = __ballot(hit);
+          if (mk) {
+            const unsigned slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            // class 16m + 4q + e, or 64 + q on the fifth tile: (64 + q) - 4q = 64 - 3q
+            const unsigned lo = m < 4 ? pixq[nt] + ((unsigned)(16 * m + e) << 17) : pixq[nt] + ((unsigned)(64 - 3 * q) << 17);
+            if (hit && slot < (unsigned)KEY_CAP)
+              cwave[slot] = ((unsigned long long)(__float_as_uint(pvv) | 0x80000000u) << 32) | lo;
+            wcnt += __builtin_popcountll(mk);
+          }
+        }
+      }
+    });
+    if (wcnt > (unsigned)KEY_CAP) {  // keys were dropped: exactness now rests on the materialising launch
+      if (lane == 0) atomicOr(&a.cand_cnt[a.n], 1u);
+      wcnt = KEY_CAP;
+    }
+  };
+
+  // ---- one phase: 72 MFMA slots on the common tiles with the finished phase's ops beside them, the fifth tile of a
+  //      leader phase, then the hit loop and the barrier ------------------------------------------------------------
+  auto phase_body = [&](f32x4(&ACC)[NT][MT], f32x4(&PV)[NT][MT], int b) __attribute__((always_inline)) {
+    const bool leader = (b & 3) == 0;
+    const int bprev = b - 1;
+    // the finished phase was a short one: its class 64+q value waits in the group's fifth-tile sums
+    if ((bprev & 3) != 0 && bprev >= 0) {
+      const int j = (bprev & 3) - 1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) PV[nt][MT - 1][0] = j == 0 ? x4r[nt][0] : (j == 1 ? x4r[nt][1] : x4r[nt][2]);
+    }
+    const f32x4* wl = reinterpret_cast<const f32x4*>(smem_raw + (b & 1) * SLOT_BYTES) + lane;
+    f32x4 af[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) af[m] = wl[m * 64];
+    static_for<NSLOT>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int g = I / 8, m = (I % 8) / 2, nt = I % 2;
+      const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);
+      // (the MFMA is pure arithmetic too: pinned from above by its own operand -- the fragment for the first k group,
+      //  the accumulator afterwards, whose pin eight slots later also bounds how far the MFMA before it may sink; that
+      //  pin reads a result finished long ago, so it costs no hazard wait)
+      if constexpr (FLM_ABLATE & 512) {
+        FLM_PIN(af[m]);
+      } else if constexpr (g == 0) {
+        if constexpr (nt == 0) FLM_PIN(af[m]);
+        ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      } else {
+        FLM_PIN(ACC[nt][m]);
+        ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, ACC[nt][m], 0, 0, 0);
+      }
+      if constexpr (nt == 1 && g + 1 < G) af[m] = wl[((g + 1) * MT + m) * 64];  // reloaded after its last use
+      if constexpr (!(FLM_ABLATE & 256))
+      static_for<kSched.first[I + 1] - kSched.first[I]>([&](auto jc) __attribute__((always_inline)) {
+        epi_op(std::integral_constant<int, kSched.first[I] + decltype(jc)::value>{}, PV, bprev);
+      });
+      // the next phase's pieces: requested in the first slots -- its ring slot has been free since this phase's barrier,
+      // and the requests then have the whole phase to land
+      if constexpr (I < 6) {
+        if (b + 1 < nph && !(FLM_ABLATE & 1024)) dma_issue(b + 1, wave + WAVES * I);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (leader) {
+      f32x4 t4 = wl[4 * 64];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 cur = t4;
+        if (g + 1 < G) t4 = wl[((g + 1) * MT + 4) * 64];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);
+          if (g == 0)
+            ACC[nt][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else
+            ACC[nt][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), xb, ACC[nt][4], 0, 0, 0);
+        }
+      }
+    }
+    if (!(FLM_ABLATE & 128)) hit_loop(PV, bprev);
+    if (leader) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        x4r[nt][0] = ACC[nt][4][1];
+        x4r[nt][1] = ACC[nt][4][2];
+        x4r[nt][2] = ACC[nt][4][3];
+      }
+    }
+    if (!(FLM_ABLATE & 64)) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // this wave's pieces of the next phase are in LDS
+      __syncthreads();
+    }
+  };
+
+  if (FLM_ABLATE & 32) return;  // (prologue only)
+  for (int b = 0; b < nph; b += 2) {  // s is a multiple of 4 (shared fifth-tile layout): even phases accumulate in set A
+    phase_body(accA, accB, b);
+    phase_body(accB, accA, b + 1);
+  }
+  {  // drain: the last phase (a short one, set B)
+    const int bprev = nph - 1, j = (bprev & 3) - 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accB[nt][MT - 1][0] = j == 0 ? x4r[nt][0] : (j == 1 ? x4r[nt][1] : x4r[nt][2]);
+    static_for<NOPS>([&](auto kc) __attribute__((always_inline)) { epi_op(kc, accB, bprev); });
+    hit_loop(accB, bprev);
+  }
+  cand_flush();
+}
+
+#undef FLM_PIN
+
+static std::atomic<int> g_cand8_rpw{0};  // A/B knob "bf16_cand8_rows": 0 = automatic, else phase rows per workgroup (1, 2, 4, 8)
+void convt_cand8_rows(int rpw) { g_cand8_rpw.store(rpw, std::memory_order_relaxed); }
+
+static int launch_cand8(hipStream_t st, ConvTArgs a) {
+  using namespace cand8;
+  static FuncAttrOnce attr;
+  FLM_FUNC_ATTR_ONCE(attr, (&up3_cand8_bf16_kernel), LDS_BYTES);
+  a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 16 * NT) * 16 * NT;  // per-face padding at wave granularity
+  const long long pos = (long long)a.n * a.ppf;
+  const int xblocks = (int)((pos + WAVES * 16 * NT - 1) / (WAVES * 16 * NT));
+  a.rpw = convt_rows_per_wg(xblocks, a.s, 256, g_cand8_rpw.load(std::memory_order_relaxed));  // one workgroup per CU
+  up3_cand8_bf16_kernel<<<dim3(xblocks, a.s / a.rpw), WAVES * 64, LDS_BYTES, st>>>(a);
+  FLM_LAUNCH_CHECK("up3_cand8_bf16_kernel");
+  return FLM_OK;
+}
+
 template <int MT, int G, bool BF, int NT = 1, int MODE = 0, bool SHARE = false>
 static int launch_t(hipStream_t st, ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
@@ -611,7 +1040,12 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
     a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 64 * NT) * 64 * NT;
     xblocks = a.n * (a.ppf / (64 * NT));
   }
-  dim3 grid(xblocks, a.sub ? 1 : a.s);
+  int rows = 1;
+  if (!a.sub) {
+    rows = convt_rows_per_wg(xblocks, a.s, 512);  // two workgroups per CU
+    a.nb = rows * a.s;
+  }
+  dim3 grid(xblocks, a.sub ? 1 : a.s / rows);
   convt_kernel<MT, G, BF, NT, MODE, SHARE><<<grid, 256, lds, st>>>(a);
   FLM_LAUNCH_CHECK("convt_kernel");
   return FLM_OK;
@@ -623,6 +1057,11 @@ int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub) {
   const int nt = g.bf16 ? 2 : 1;
   return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt) * sub;
 }
+
+// A/B knob (flm_set_tuning "bf16_cand8"): 1 (default) the 8-wave kernel above for the bf16 candidate launch, 0 the generic
+// kernel; same keys either way, so it never changes results or layouts
+static std::atomic<int> g_cand8{1};
+void convt_cand8_enable(int on) { g_cand8.store(on, std::memory_order_relaxed); }
 
 int convt_candidates_supported(const ConvTGeom& g) {
   return g.C == 68 && ((g.bf16 && g.G == 9) || (!g.bf16 && g.G == 17));
@@ -662,6 +1101,8 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
       set_error("convt: the candidate epilogue is built for strides that are multiples of 4");
       return FLM_ERR_UNSUPPORTED;
     }
+    if (d.g.bf16 && g_cand8.load(std::memory_order_relaxed) && (d.s & 3) == 0 && d.s >= 4 && (long long)d.s * d.s * cand8::SLOT_BYTES < 0x7fffffffll)
+      return launch_cand8(st, a);
     return d.g.bf16 ? launch_t<5, 9, true, 2, 1, true>(st, a) : launch_t<5, 17, false, 1, 1, true>(st, a);
   }
   if (d.epilogue == 4) {
