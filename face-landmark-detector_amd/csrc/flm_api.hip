@@ -174,8 +174,9 @@ static int check_fcn8_shape(int n, int h, int w, int C, int dtype) {
     set_error("fcn8: n_classes must be in [1,%d] (got %d)", kMaxClasses, C);
     return FLM_ERR_SHAPE;
   }
-  if ((long long)n * (h + 8) * (w + 8) * C >= (1ll << 40)) {
-    set_error("fcn8: batch too large");
+  // (factors bounded first: the product below then fits 64 bits -- found by the UBSan sweep, tests/test_abi_sanitized.py)
+  if (n > (1 << 24) || h > (1 << 15) || w > (1 << 15) || (long long)n * (h + 32) * (w + 32) * C >= (1ll << 40)) {
+    set_error("fcn8: batch too large (n=%d h=%d w=%d: at most 2^40 output values per call)", n, h, w);
     return FLM_ERR_SHAPE;
   }
   return FLM_OK;

@@ -2,6 +2,9 @@
 // kernels are compared with in DESIGN.md section 5.  Operands live in registers (random bit patterns, not zeros:
 // the chip holds a lower clock on random data), accumulators are independent, one or two waves per SIMD, every CU
 // busy; reports TFLOP/s from wall time and the in-kernel clock (s_memtime / s_memrealtime, 100 MHz reference).
+// The MFMAs are written as inline assembly with the accumulator tied in place: through the builtin hipcc moved the
+// 16x16x32 accumulators between AGPRs and VGPRs inside the loop (a dozen v_accvgpr copies per MFMA), which made that
+// row of round 1's table read 45 cycles per MFMA instead of the pipe's 16 (MI355X_MICROARCH.md).
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -29,7 +32,8 @@ __global__ __launch_bounds__(256) void peak_kernel(const unsigned* __restrict__ 
     const bf16x8 a = __builtin_bit_cast(bf16x8, ra), b = __builtin_bit_cast(bf16x8, rb);
     for (int it = 0; it < iters; ++it)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     for (int i = 0; i < 4; ++i) res += acc[i][0];
   } else if (KIND == 1) {  // v_mfma_f32_16x16x32_bf16, 8 independent accumulators
     f32x4 acc[8];
@@ -37,7 +41,8 @@ __global__ __launch_bounds__(256) void peak_kernel(const unsigned* __restrict__ 
     const bf16x8 a = __builtin_bit_cast(bf16x8, ra), b = __builtin_bit_cast(bf16x8, rb);
     for (int it = 0; it < iters; ++it)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the last results land before they are read)
     for (int i = 0; i < 8; ++i) res += acc[i][0];
   } else {  // v_mfma_f32_32x32x2_f32, 4 independent accumulators
     f32x16 acc[4];
@@ -45,7 +50,8 @@ __global__ __launch_bounds__(256) void peak_kernel(const unsigned* __restrict__ 
     const float a = __uint_as_float(ra.x), b = __uint_as_float(rb.x);
     for (int it = 0; it < iters; ++it)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     for (int i = 0; i < 4; ++i) res += acc[i][0];
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
