@@ -234,13 +234,17 @@ int flm_set_tuning(const char* key, int value) {
               "flm_fcn_workspace_bytes_opts / flm_fcn_forward_opts", key);
     return FLM_ERR_ARG;
   }
-  if (!strcmp(key, "bf16_cand8")) {  // bf16 candidate launch of up3: 1 the 8-wave kernel (default), 0 the generic one
+  if (!strcmp(key, "up3_cand8")) {  // candidate launch of up3: bit 0 bf16, bit 1 fp32 take the 8-wave kernel (default 3)
+    if (value < 0 || value > 3) {
+      set_error("flm_set_tuning: up3_cand8 must be in [0,3]");
+      return FLM_ERR_ARG;
+    }
     flm::convt_cand8_enable(value);
     return FLM_OK;
   }
-  if (!strcmp(key, "bf16_cand8_rows")) {  // phase rows per workgroup of that kernel: 0 automatic, else 1, 2, 4 or 8
+  if (!strcmp(key, "up3_cand8_rows")) {  // phase rows per workgroup of that kernel: 0 automatic, else 1, 2, 4 or 8
     if (value < 0 || value > 32 || (value & (value - 1))) {
-      set_error("flm_set_tuning: bf16_cand8_rows must be 0 or a power of two <= 32");
+      set_error("flm_set_tuning: up3_cand8_rows must be 0 or a power of two <= 32");
       return FLM_ERR_ARG;
     }
     flm::convt_cand8_rows(value);

@@ -203,8 +203,8 @@ __host__ __device__ inline int convt_share_layout(const ConvTGeom& g, int s) {
   return g.C == 68 && (g.bf16 ? g.G == 9 : g.G == 17) && (s % 4) == 0;
 }
 int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub);
-void convt_cand8_enable(int on);  // A/B knob "bf16_cand8"
-void convt_cand8_rows(int rpw);    // A/B knob "bf16_cand8_rows"
+void convt_cand8_enable(int mask);  // A/B knob "up3_cand8"
+void convt_cand8_rows(int rpw);     // A/B knob "up3_cand8_rows"
 int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau);
 
 // (activations fp32, or bf16 when `bf16`)

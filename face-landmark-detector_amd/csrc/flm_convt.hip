@@ -627,60 +627,76 @@ static int convt_rows_per_wg(int xblocks, int s, int wg_slots, int forced = 0) {
 }
 
 // =====================================================================================================================
-// up3 in landmark mode (epilogue 3) for the bf16 68-class model: a kernel of its own (`cand8`).
+// up3 in landmark mode (epilogue 3) for the 68-class model: a kernel of its own (`cand8`), bf16 and fp32.
 //
-// What the generic kernel above spends its time on in this mode (tools/ablate_up3.py, batch 512: 2.63 ms): the weight
-// ring alone -- global -> registers -> ds_write -> barrier, three chunks per phase, 13.6 GB per launch out of L2 -- takes
-// 1.40 ms with everything else compiled out; the ten threshold reads per phase each expose an LDS round trip; the
-// candidate code, inlined at 160 sites, pushes the loop past the instruction cache (68 KB).  Here:
-//   * 8 waves per workgroup, one workgroup per CU: the phase's weights are fetched once per 256 positions (half the
-//     bytes), straight into LDS by LDS-DMA (no staging registers, no ds_write pass), in whole-phase slots -- ONE
-//     barrier per phase instead of three; the fifth class tile of the three short phases of a group is not fetched;
-//   * per-face padding at wave granularity (32 positions: 1089 -> 1120 instead of 1152 per face); a wave's thresholds
-//     live in 20 registers (the staging registers' room), its face may differ from its neighbours';
-//   * the softmax / threshold test of phase b-1 is cut into 134 small ops dealt over the 72 MFMA slots of phase b by
-//     cost (compile-time schedule, order pinned with sched_barrier): both waves of a SIMD run the same even mix of
-//     matrix and vector work, so they need not drift apart to overlap;
-//   * hits (about one value in 500) only set a bit per (pixel tile, class tile) group; ONE shared loop per phase then
-//     re-tests the flagged groups and appends the keys -- the code that was inlined 160 times exists twice.
-// Arithmetic per value is the generic kernel's, operation by operation (same MFMA order over k, same max / exp2 / sum
-// order / rcp / product), so keys carry the very bits its materialising and sampling launches produce: thresholds taken
-// from the sampling launch stay valid, and the landmark result is bit-identical (tests/test_gpu_candidates.py).
+// What the generic kernel above spends its time on in this mode (tools/ablate_up3.py, bf16 batch 512: 2.63 ms): the
+// weight ring alone -- global -> registers -> ds_write -> barrier, three chunks per phase, 13.6 GB per launch out of L2 --
+// takes 1.40 ms with everything else compiled out; the ten threshold reads per phase each expose an LDS round trip; the
+// candidate code, inlined at 160 sites, pushes the loop past the instruction cache (68 KB); and every workgroup reloads
+// its X fragments for just one phase row.  Here:
+//   * 8 waves per workgroup, one workgroup per CU: a ring step's weights are fetched once per 256 (fp32: 128) positions
+//     -- half the bytes -- straight into LDS by LDS-DMA (no staging registers, no ds_write pass), in 45 KiB steps: a
+//     whole phase in bf16 (ONE barrier per phase instead of three), half a phase in fp32 (k groups 0..8 | 9..16); the
+//     fifth class tile of the three short phases of a group is not fetched;
+//   * a workgroup walks several phase rows (up to all 64 phases) with the same X fragments (convt_rows_per_wg);
+//   * per-face padding at wave granularity (bf16: 1089 -> 1120 positions per face, fp32: 1104, instead of 1152); a wave's
+//     thresholds live in 20 registers (the staging registers' room), its face may differ from its neighbours';
+//   * the softmax / threshold test of phase b-1 is cut into small ops dealt over the MFMA slots of phase b by cost
+//     (compile-time schedule, order pinned): both waves of a SIMD run the same even mix of matrix and vector work;
+//   * hits (about one value in 500) only set a bit per (pixel tile, class tile) group; one lean loop per phase then
+//     re-tests the flagged groups and appends the keys -- the code that was inlined 160 times exists 20 times.
+// Arithmetic per value is the generic kernel's, operation by operation (same MFMA order over k, same max / exp / sum
+// order / reciprocal / product), so keys carry the very bits its materialising and sampling launches produce: thresholds
+// taken from the sampling launch stay valid, and the landmark result is bit-identical (tests/test_gpu_candidates.py).
+// bf16 batch 512: 2.63 -> 2.12 ms.
 // =====================================================================================================================
 namespace cand8 {
-constexpr int MT = 5, G = 9, NT = 2, WAVES = 8;
-constexpr int PIECE = 1024;                 // one (g, m) fragment tile: 64 lanes x 16 bytes
-constexpr int SLOT_BYTES = G * MT * PIECE;  // 46,080 bytes: the weights of a whole phase
-constexpr int KEY_CAP = 512;                // keys a wave holds in LDS between flushes
-constexpr int NSLOT = G * 4 * NT;           // 72 MFMAs of the four common class tiles per phase and wave
+constexpr int MT = 5, WAVES = 8;
+constexpr int PIECE = 1024;             // one (g, m) fragment tile: 64 lanes x 16 bytes
+constexpr int STEP_G = 9;               // k groups per ring step
+constexpr int SLOT_BYTES = STEP_G * MT * PIECE;  // 46,080 bytes: a ring step (bf16: a whole phase)
+constexpr int KEY_CAP = 512;            // keys a wave holds in LDS between flushes
 constexpr size_t LDS_BYTES = 2 * (size_t)SLOT_BYTES + (size_t)WAVES * KEY_CAP * 8;
 
-// ---- the epilogue of one phase as a list of small ops (both pixel tiles interleaved: op k works on nt = k & 1) -------
-//   A  18  running class maximum, two values per v_max3        B  2  cross-lane-group maximum, -max*log2(e)
-//   C  34  e = exp2(fma(x, log2(e), -max*log2(e)))              D  34  sum += e (the generic kernel's order)
-//   E   2  cross-lane-group sum, reciprocal, pixel validity     F  34  p = e * (1/sum)
-//   G  10  p >= tau for the 4 (1) values of a class tile -> one bit per group          (A starts at op 0)
-constexpr int B0 = 18, C0 = 20, D0 = 54, E0 = 88, F0 = 90, G0 = 124, NOPS = 134;
-constexpr int op_cost(int k) {  // issue cycles / 4, roughly (v_exp_f32 8, the rest 4)
-  return k < B0 ? 1 : k < C0 ? 7 : k < D0 ? 3 : k < E0 ? 1 : k < F0 ? 8 : k < G0 ? 1 : 5;
-}
-struct EpiSched {
-  int first[NSLOT + 1];  // ops [first[s], first[s+1]) run beside MFMA slot s
-  constexpr EpiSched() : first() {
-    int total = 0;
-    for (int k = 0; k < NOPS; ++k) total += op_cost(k);
-    int k = 0, cum = 0;
-    for (int sl = 0; sl < NSLOT; ++sl) {
-      first[sl] = k;
-      // slot sl takes ops while the cumulated cost stays within its share (the last slots end a little early: the
-      // shared hit loop follows them)
-      while (k < NOPS && (cum + op_cost(k)) * (long long)NSLOT <= (long long)total * (sl + 1)) cum += op_cost(k++);
-    }
-    first[NSLOT] = NOPS;
+template <bool BF>
+struct Cfg {
+  static constexpr int G = BF ? 9 : 17;      // k groups: 32 deep (bf16, one 16x16x32 MFMA) or 16 deep (fp32, four 16x16x4)
+  static constexpr int NT = BF ? 2 : 1;      // pixel tiles of 16 per wave
+  static constexpr int KM = BF ? 1 : 4;      // MFMAs per (k group, class tile, pixel tile)
+  static constexpr int NSTEP = (G + STEP_G - 1) / STEP_G;  // ring steps per phase
+  static constexpr int PHASE_BYTES = G * MT * PIECE;
+  static constexpr int NSLOT = G * 4 * NT * KM;            // MFMAs of the four common class tiles per phase and wave
+  // ---- the epilogue of one phase as a list of small ops (pixel tiles interleaved: op k of a stage works on nt = k % NT)
+  //   A  9 NT  running class maximum, two values per v_max3     B  NT  cross-lane-group maximum, -max*log2(e)
+  //   C 17 NT  e = exp(x - max)                                  D 17 NT  sum += e (the generic kernel's order)
+  //   E    NT  cross-lane-group sum, reciprocal, pixel validity  F 17 NT  p = e * (1/sum)
+  //   G  5 NT  p >= tau for the 4 (1) values of a class tile -> one bit per group
+  static constexpr int B0 = 9 * NT, C0 = B0 + NT, D0 = C0 + 17 * NT, E0 = D0 + 17 * NT, F0 = E0 + NT, G0 = F0 + 17 * NT,
+                       NOPS = G0 + 5 * NT;
+  static constexpr int op_cost(int k) {  // issue cycles / 4, roughly (bf16: v_exp_f32 8; fp32: the accurate expf, a true division)
+    return k < B0 ? 1 : k < C0 ? 7 : k < D0 ? (BF ? 3 : 20) : k < E0 ? 1 : k < F0 ? (BF ? 8 : 16) : k < G0 ? 1 : 5;
   }
 };
-constexpr EpiSched kSched{};
-static_assert(kSched.first[NSLOT - 1] <= NOPS, "schedule");
+template <bool BF>
+struct EpiSched {
+  int first[Cfg<BF>::NSLOT + 1];  // ops [first[s], first[s+1]) run beside MFMA slot s
+  constexpr EpiSched() : first() {
+    using C = Cfg<BF>;
+    int total = 0;
+    for (int k = 0; k < C::NOPS; ++k) total += C::op_cost(k);
+    int k = 0, cum = 0;
+    for (int sl = 0; sl < C::NSLOT; ++sl) {
+      first[sl] = k;
+      // slot sl takes ops while the cumulated cost stays within its share
+      while (k < C::NOPS && (cum + C::op_cost(k)) * (long long)C::NSLOT <= (long long)total * (sl + 1)) cum += C::op_cost(k++);
+    }
+    first[C::NSLOT] = C::NOPS;
+  }
+};
+template <bool BF>
+struct Sched {
+  static constexpr EpiSched<BF> k{};
+};
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -702,8 +718,11 @@ __device__ __forceinline__ void dma_piece(dma_srd srd, unsigned lds_addr, unsign
 }
 }  // namespace cand8
 
-__global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  // 8 waves = 2 per SIMD: 256 registers each
+template <bool BF>
+__global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 waves = 2 per SIMD: 256 registers each
   using namespace cand8;
+  using C = Cfg<BF>;
+  constexpr int G = C::G, NT = C::NT, KM = C::KM, NSTEP = C::NSTEP, NOPS = C::NOPS;
   if (a.gate && *a.gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef __attribute__((address_space(3))) char lds_char;
@@ -715,16 +734,16 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  
   unsigned wcnt = 0;
 
   const int s = a.s;
-  const int row0 = blockIdx.y * a.rpw;   // this workgroup walks phase rows row0 .. row0 + rpw - 1, phases t = 0 .. rpw*s - 1
+  const int row0 = blockIdx.y * a.rpw;  // this workgroup walks phase rows row0 .. row0 + rpw - 1: phases t = 0 .. rpw*s - 1
   const int nph = a.rpw * s;
   const int ls = a.ls;
-  // ---- this wave's 32 positions: one face (ppf is a multiple of 32) ------------------------------------------------
+  // ---- this wave's 16 NT positions: one face (ppf is a multiple of 16 NT) --------------------------------------------
   const int wi1 = a.wi + 1, hi1 = a.hi + 1;
   const int p0 = (blockIdx.x * WAVES + wave) * 16 * NT;
   const int wimg = p0 / a.ppf;
   const bool wlive = wimg < a.n;
   bool pvalid[NT];
-  int oy0[NT], ox0[NT];   // output pixel of phase (a0, b0): (oy0 + a0, ox0 + b0)
+  int oy0[NT], ox0[NT];  // output pixel of phase (a0, b0): (oy0 + a0, ox0 + b0)
   int i0[NT], j0[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -750,40 +769,50 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  
     tq[m] = make_float4(t[0], t[1], t[2], t[3]);
   }
 
-  // ---- X fragments: xf[nt][g] = bf16(x[tap(k8)][c(k8)..+7]), k8 = 32g + 8q, as the generic kernel -------------------
-  float4 xf[NT][G];
+  // ---- X fragments, as the generic kernel: bf16: xf[nt][g] = bf16(x[tap(k8)][c(k8)..+7]), k8 = 32g + 8q;
+  //      fp32: xf[nt][g] = x[tap(k4)][c(k4)..+3], k4 = 16g + 4q ----------------------------------------------------------
+  f32x4 xf[NT][G];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int k0 = 32 * g + 8 * q;
+      constexpr int EPL = BF ? 8 : 4;
+      const int k0 = 4 * EPL * g + EPL * q;
       const int tap = k0 / a.Cp, c = k0 % a.Cp;
       const int ii = i0[nt] - (tap >> 1), jj = j0[nt] - (tap & 1);
       const bool ok = wlive && tap < 4 && (unsigned)ii < (unsigned)a.hi && (unsigned)jj < (unsigned)a.wi &&
                       (p0 % a.ppf + nt * 16 + r) < wi1 * hi1;
       const size_t off = ok ? (((size_t)wimg * a.hi + ii) * a.wi + jj) * a.Cp + c : 0;
       const float4 v0 = *reinterpret_cast<const float4*>(a.x + off);
-      const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
-      bf16x8 t;
-      t[0] = (__bf16)(ok ? v0.x : 0.f); t[1] = (__bf16)(ok ? v0.y : 0.f);
-      t[2] = (__bf16)(ok ? v0.z : 0.f); t[3] = (__bf16)(ok ? v0.w : 0.f);
-      t[4] = (__bf16)(ok ? v1.x : 0.f); t[5] = (__bf16)(ok ? v1.y : 0.f);
-      t[6] = (__bf16)(ok ? v1.z : 0.f); t[7] = (__bf16)(ok ? v1.w : 0.f);
-      xf[nt][g] = __builtin_bit_cast(float4, t);
+      if constexpr (BF) {
+        const float4 v1 = *reinterpret_cast<const float4*>(a.x + off + 4);
+        bf16x8 t;
+        t[0] = (__bf16)(ok ? v0.x : 0.f); t[1] = (__bf16)(ok ? v0.y : 0.f);
+        t[2] = (__bf16)(ok ? v0.z : 0.f); t[3] = (__bf16)(ok ? v0.w : 0.f);
+        t[4] = (__bf16)(ok ? v1.x : 0.f); t[5] = (__bf16)(ok ? v1.y : 0.f);
+        t[6] = (__bf16)(ok ? v1.z : 0.f); t[7] = (__bf16)(ok ? v1.w : 0.f);
+        xf[nt][g] = __builtin_bit_cast(f32x4, t);
+      } else {
+        xf[nt][g] = (f32x4){ok ? v0.x : 0.f, ok ? v0.y : 0.f, ok ? v0.z : 0.f, ok ? v0.w : 0.f};
+      }
     }
 
-  // ---- weight ring: two whole-phase slots filled by LDS-DMA; wave w moves pieces w, w+8, ... of the next phase --------
+  // ---- weight ring: two 45 KiB steps filled by LDS-DMA; wave w moves pieces w, w+8, ... of the next step ---------------
   const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wf);
   const dma_srd wsrd = (dma_srd){(int)(unsigned)wbase, (int)(unsigned)((wbase >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
   const unsigned voff = (unsigned)lane * 16u;
-  // piece i of the workgroup's phase t = b -> (g, m): a leader phase (t % 4 == 0) has 45 pieces, a short one the 36 of
-  // tiles 0..3; the packed phases of consecutive rows are consecutive, so phase t is packed phase row0*s + t
-  auto dma_issue = [&](int b, int i) __attribute__((always_inline)) {
-    const bool leader = (b & 3) == 0;
-    const int np = leader ? G * MT : G * 4;
+  // Ring step u = t * NSTEP + st: k groups [st * 9, min(G, st * 9 + 9)) of the workgroup's phase t (packed phase
+  // row0*s + t: consecutive rows are consecutive in the packed array).  Piece i -> (g, m): a leader phase (t % 4 == 0)
+  // moves five class tiles per k group, a short one the four common ones.
+  auto dma_issue = [&](int u, int i) __attribute__((always_inline)) {
+    const int t = NSTEP == 1 ? u : u >> 1, st = NSTEP == 1 ? 0 : u & 1;
+    const bool leader = (t & 3) == 0;
+    const int ng = st == 0 ? (G < STEP_G ? G : STEP_G) : G - STEP_G;
+    const int np = ng * (leader ? MT : 4);
     if (i < np) {
-      const int pc = leader ? i : (i >> 2) * MT + (i & 3);
-      dma_piece(wsrd, ring_lds + (unsigned)((b & 1) * SLOT_BYTES + pc * PIECE), voff, (row0 * s + b) * SLOT_BYTES + pc * PIECE);
+      const int pc = leader ? i : (i >> 2) * MT + (i & 3);  // piece of the step: (g - g0) * 5 + m
+      dma_piece(wsrd, ring_lds + (unsigned)((u & 1) * SLOT_BYTES + pc * PIECE), voff,
+                (row0 * s + t) * C::PHASE_BYTES + (st * STEP_G * MT + pc) * PIECE);
     }
   };
 #pragma unroll
@@ -822,49 +851,50 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) mx[nt] = nmxl[nt] = sum[nt] = rs[nt] = 0.f;
 
-  // op K of the list above on the finished phase's values PV; bprev = its b0 (< 0: no phase yet, nothing may hit)
+  // op K of the list above on the finished phase's values PV; bprev = its index t (< 0: no phase yet, nothing may hit)
   // (pin: an empty volatile asm on a value.  The ops are pure arithmetic, which LLVM places wherever the data flow
   //  allows -- it regrouped the exps and the products into blocks between the MFMAs -- and sched_barrier only fences the
   //  machine scheduler; a volatile asm keeps its place among the other side-effecting statements, so an op whose RESULT is
   //  pinned is issued no later than the slot it was written in, and nothing makes hipcc issue it earlier.  Pinning the
-  //  inputs as well cost a hazard s_nop around every pin: 585 in the kernel against 265 this way.)
+  //  inputs as well cost a hazard s_nop around every pin: 585 in the bf16 kernel against 265 this way.)
 #define FLM_PIN(x) asm volatile("" : "+v"(x))
   auto epi_op = [&](auto kc, f32x4(&PV)[NT][MT], int bprev) __attribute__((always_inline)) {
     constexpr int K = decltype(kc)::value;
-    if constexpr (K < B0) {
-      constexpr int nt = K & 1, j = K >> 1;
+    if constexpr (K < C::B0) {
+      constexpr int nt = K % NT, j = K / NT;
       if constexpr (j == 0) mx[nt] = max_raw(PV[nt][0][0], PV[nt][0][1]);
       else if constexpr (j < 8) mx[nt] = max3_raw(mx[nt], PV[nt][j >> 1][2 * (j & 1)], PV[nt][j >> 1][2 * (j & 1) + 1]);
       else mx[nt] = max_raw(mx[nt], PV[nt][4][0]);
       FLM_PIN(mx[nt]);
-    } else if constexpr (K < C0) {
-      constexpr int nt = (K - B0) & 1;
+    } else if constexpr (K < C::C0) {
+      constexpr int nt = (K - C::B0) % NT;
       mx[nt] = reduce_q_max(mx[nt]);
       nmxl[nt] = -mx[nt] * 1.44269504088896340736f;
       FLM_PIN(nmxl[nt]);
-    } else if constexpr (K < D0) {
-      constexpr int nt = (K - C0) & 1, i = (K - C0) >> 1, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
-      float v = softmax_exp<true>(PV[nt][m][e], mx[nt], nmxl[nt]);
+    } else if constexpr (K < C::D0) {
+      constexpr int nt = (K - C::C0) % NT, i = (K - C::C0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+      float v = softmax_exp<BF>(PV[nt][m][e], mx[nt], nmxl[nt]);
       FLM_PIN(v);
       PV[nt][m][e] = v;
-    } else if constexpr (K < E0) {
-      constexpr int nt = (K - D0) & 1, i = (K - D0) >> 1, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+    } else if constexpr (K < C::E0) {
+      constexpr int nt = (K - C::D0) % NT, i = (K - C::D0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
       if constexpr (i == 0) sum[nt] = 0.f + PV[nt][m][e];
       else sum[nt] += PV[nt][m][e];
       FLM_PIN(sum[nt]);
-    } else if constexpr (K < F0) {
-      constexpr int nt = (K - E0) & 1;
+    } else if constexpr (K < C::F0) {
+      constexpr int nt = (K - C::E0) % NT;
       const float sq = reduce_q_sum(sum[nt]);
       const bool ok = pvalid[nt] && bprev >= 0 && oy0[nt] + row0 + (bprev >> ls) < a.ho && ox0[nt] + (bprev & (s - 1)) < a.wo;
-      rs[nt] = ok ? __builtin_amdgcn_rcpf(sq) : 0.f;
+      const float inv = BF ? __builtin_amdgcn_rcpf(sq) : 1.0f / sq;
+      rs[nt] = ok ? inv : 0.f;
       FLM_PIN(rs[nt]);
-    } else if constexpr (K < G0) {
-      constexpr int nt = (K - F0) & 1, i = (K - F0) >> 1, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+    } else if constexpr (K < C::G0) {
+      constexpr int nt = (K - C::F0) % NT, i = (K - C::F0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
       float v = PV[nt][m][e] * rs[nt];
       FLM_PIN(v);
       PV[nt][m][e] = v;
     } else {
-      constexpr int nt = (K - G0) & 1, m = (K - G0) >> 1;
+      constexpr int nt = (K - C::G0) % NT, m = (K - C::G0) / NT;
       unsigned long long mk = __ballot(PV[nt][m][0] >= tq[m].x);
       if constexpr (m < 4) {
         mk |= __ballot(PV[nt][m][1] >= tq[m].y);
@@ -874,9 +904,9 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  
       hitmask |= mk ? 1u << (nt * MT + m) : 0u;  // (scalar: the products it tests are pinned in their slots)
     }
   };
-  // The flagged groups of the finished phase: re-test, append keys (value order bits << 32 | class << 17 | pixel).  Ten
-  // copies of the append code per phase body (one per group, compile-time registers) instead of the generic kernel's
-  // forty, each reached through one wave-uniform bit test and only when some group was flagged.  Kept lean -- per hit
+  // The flagged groups of the finished phase: re-test, append keys (value order bits << 32 | class << 17 | pixel).  One
+  // copy of the append code per group and phase body (compile-time registers) instead of the generic kernel's four per
+  // group, each reached through one wave-uniform bit test and only when some group was flagged.  Kept lean -- per hit
   // value: the ballot, two mbcnt, the key halves (p > 0, so its order bits are its bits with the sign set; class and
   // pixel add up from per-lane terms computed once per call), one ds_write_b64.  Room is made once per call (a flush
   // when the wave's region is half full); a call that still runs out (more than 256 hits of one wave in one phase: flat
@@ -916,78 +946,109 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  
     }
   };
 
-  // ---- one phase: 72 MFMA slots on the common tiles with the finished phase's ops beside them, the fifth tile of a
-  //      leader phase, then the hit loop and the barrier ------------------------------------------------------------
-  auto phase_body = [&](f32x4(&ACC)[NT][MT], f32x4(&PV)[NT][MT], int b) __attribute__((always_inline)) {
+  // one MFMA group of a (k group, class tile, pixel tile): bf16 one 16x16x32, fp32 component KC of four 16x16x4; FIRST:
+  // the accumulator starts from zero
+  auto mfma_step = [&](auto kcc, auto firstc, f32x4& acc, const f32x4& af, const f32x4& xv) __attribute__((always_inline)) {
+    constexpr int KC = decltype(kcc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+      (void)KC;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, xv), FIRST ? zero : acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[KC], xv[KC], FIRST ? zero : acc, 0, 0, 0);
+    }
+  };
+
+  // ---- one ring step ST of phase b: its MFMA slots on the common tiles with the finished phase's ops beside them, the
+  //      fifth tile of a leader phase, after the phase's last step the hit loop; then the wait and the barrier ----------
+  // Slot order inside a k group: bf16 (m, nt); fp32 (component, m) -- each accumulator sees k in ascending order, as in the
+  // generic kernel.
+  auto step_body = [&](auto stc, f32x4(&ACC)[NT][MT], f32x4(&PV)[NT][MT], int b) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr int g0 = ST * STEP_G, g1 = (g0 + STEP_G < G) ? g0 + STEP_G : G;
+    constexpr int SPG = 4 * NT * KM;  // slots per k group
     const bool leader = (b & 3) == 0;
     const int bprev = b - 1;
-    // the finished phase was a short one: its class 64+q value waits in the group's fifth-tile sums
-    if ((bprev & 3) != 0 && bprev >= 0) {
-      const int j = (bprev & 3) - 1;
+    const int u = b * NSTEP + ST;
+    if constexpr (ST == 0) {
+      // the finished phase was a short one: its class 64+q value waits in the group's fifth-tile sums
+      if ((bprev & 3) != 0 && bprev >= 0) {
+        const int j = (bprev & 3) - 1;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) PV[nt][MT - 1][0] = j == 0 ? x4r[nt][0] : (j == 1 ? x4r[nt][1] : x4r[nt][2]);
+        for (int nt = 0; nt < NT; ++nt) PV[nt][MT - 1][0] = j == 0 ? x4r[nt][0] : (j == 1 ? x4r[nt][1] : x4r[nt][2]);
+      }
     }
-    const f32x4* wl = reinterpret_cast<const f32x4*>(smem_raw + (b & 1) * SLOT_BYTES) + lane;
+    const f32x4* wl = reinterpret_cast<const f32x4*>(smem_raw + (u & 1) * SLOT_BYTES) + lane;
     f32x4 af[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) af[m] = wl[m * 64];
-    static_for<NSLOT>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int I = decltype(ic)::value;
-      constexpr int g = I / 8, m = (I % 8) / 2, nt = I % 2;
-      const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);
-      // (the MFMA is pure arithmetic too: pinned from above by its own operand -- the fragment for the first k group,
-      //  the accumulator afterwards, whose pin eight slots later also bounds how far the MFMA before it may sink; that
-      //  pin reads a result finished long ago, so it costs no hazard wait)
+    static_for<(g1 - g0) * SPG>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int IL = decltype(ic)::value;        // slot inside the step
+      constexpr int I = g0 * SPG + IL;               // slot inside the phase
+      constexpr int g = I / SPG, w = I % SPG;
+      constexpr int m = BF ? w / NT : w % 4, nt = BF ? w % NT : 0, kc = BF ? 0 : w / 4;
+      constexpr bool first = g == 0 && kc == 0;
+      // (the MFMA is pure arithmetic too: pinned from above by its own operand -- the fragment for the first MFMA of a
+      //  step, the accumulator afterwards, whose pin a few slots later also bounds how far the MFMA before it may sink;
+      //  that pin reads a result finished long ago, so it costs no hazard wait)
       if constexpr (FLM_ABLATE & 512) {
         FLM_PIN(af[m]);
-      } else if constexpr (g == 0) {
-        if constexpr (nt == 0) FLM_PIN(af[m]);
-        ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       } else {
-        FLM_PIN(ACC[nt][m]);
-        ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, ACC[nt][m], 0, 0, 0);
+        if constexpr (first || (IL < 4 * NT && kc == 0)) { if constexpr (nt == 0) FLM_PIN(af[m]); }
+        if constexpr (!first) FLM_PIN(ACC[nt][m]);
+        mfma_step(std::integral_constant<int, kc>{}, std::integral_constant<bool, first>{}, ACC[nt][m], af[m], xf[nt][g]);
       }
-      if constexpr (nt == 1 && g + 1 < G) af[m] = wl[((g + 1) * MT + m) * 64];  // reloaded after its last use
+      // the fragment is reloaded after its last use in the k group
+      if constexpr ((BF ? nt == NT - 1 : kc == KM - 1) && g + 1 < g1) af[m] = wl[((g + 1 - g0) * MT + m) * 64];
       if constexpr (!(FLM_ABLATE & 256))
-      static_for<kSched.first[I + 1] - kSched.first[I]>([&](auto jc) __attribute__((always_inline)) {
-        epi_op(std::integral_constant<int, kSched.first[I] + decltype(jc)::value>{}, PV, bprev);
+      static_for<Sched<BF>::k.first[I + 1] - Sched<BF>::k.first[I]>([&](auto jc) __attribute__((always_inline)) {
+        epi_op(std::integral_constant<int, Sched<BF>::k.first[I] + decltype(jc)::value>{}, PV, bprev);
       });
-      // the next phase's pieces: requested in the first slots -- its ring slot has been free since this phase's barrier,
-      // and the requests then have the whole phase to land
-      if constexpr (I < 6) {
-        if (b + 1 < nph && !(FLM_ABLATE & 1024)) dma_issue(b + 1, wave + WAVES * I);
+      // the next step's pieces: requested in the first slots -- its ring slot has been free since this step's barrier,
+      // and the requests then have the whole step to land
+      if constexpr (IL < 6) {
+        if (u + 1 < nph * NSTEP && !(FLM_ABLATE & 1024)) dma_issue(u + 1, wave + WAVES * IL);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
     if (leader) {
       f32x4 t4 = wl[4 * 64];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
+      for (int g = g0; g < g1; ++g) {
         const f32x4 cur = t4;
-        if (g + 1 < G) t4 = wl[((g + 1) * MT + 4) * 64];
+        if (g + 1 < g1) t4 = wl[((g + 1 - g0) * MT + 4) * 64];
+#pragma unroll
+        for (int kc = 0; kc < KM; ++kc)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (BF) {
+              ACC[nt][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), __builtin_bit_cast(bf16x8, xf[nt][g]),
+                                                                   g == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : ACC[nt][4], 0, 0, 0);
+            } else {
+              ACC[nt][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[kc], xf[nt][g][kc], (g == 0 && kc == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : ACC[nt][4], 0, 0, 0);
+            }
+          }
+      }
+    }
+    if constexpr (ST == NSTEP - 1) {
+      if (!(FLM_ABLATE & 128)) hit_loop(PV, bprev);
+      if (leader) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[nt][g]);
-          if (g == 0)
-            ACC[nt][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          else
-            ACC[nt][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur), xb, ACC[nt][4], 0, 0, 0);
+          x4r[nt][0] = ACC[nt][4][1];
+          x4r[nt][1] = ACC[nt][4][2];
+          x4r[nt][2] = ACC[nt][4][3];
         }
       }
     }
-    if (!(FLM_ABLATE & 128)) hit_loop(PV, bprev);
-    if (leader) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        x4r[nt][0] = ACC[nt][4][1];
-        x4r[nt][1] = ACC[nt][4][2];
-        x4r[nt][2] = ACC[nt][4][3];
-      }
-    }
     if (!(FLM_ABLATE & 64)) {
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // this wave's pieces of the next phase are in LDS
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // this wave's pieces of the next step are in LDS
       __syncthreads();
     }
+  };
+  auto phase_body = [&](f32x4(&ACC)[NT][MT], f32x4(&PV)[NT][MT], int b) __attribute__((always_inline)) {
+    static_for<NSTEP>([&](auto stc) __attribute__((always_inline)) { step_body(stc, ACC, PV, b); });
   };
 
   if (FLM_ABLATE & 32) return;  // (prologue only)
@@ -1004,22 +1065,23 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_bf16_kernel(ConvTArgs a) {  
   }
   cand_flush();
 }
-
 #undef FLM_PIN
 
-static std::atomic<int> g_cand8_rpw{0};  // A/B knob "bf16_cand8_rows": 0 = automatic, else phase rows per workgroup (1, 2, 4, 8)
+static std::atomic<int> g_cand8_rpw{0};  // A/B knob "up3_cand8_rows": 0 = automatic, else phase rows per workgroup (1, 2, 4, 8)
 void convt_cand8_rows(int rpw) { g_cand8_rpw.store(rpw, std::memory_order_relaxed); }
 
+template <bool BF>
 static int launch_cand8(hipStream_t st, ConvTArgs a) {
   using namespace cand8;
+  constexpr int NT = Cfg<BF>::NT;
   static FuncAttrOnce attr;
-  FLM_FUNC_ATTR_ONCE(attr, (&up3_cand8_bf16_kernel), LDS_BYTES);
+  FLM_FUNC_ATTR_ONCE(attr, (&up3_cand8_kernel<BF>), LDS_BYTES);
   a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 16 * NT) * 16 * NT;  // per-face padding at wave granularity
   const long long pos = (long long)a.n * a.ppf;
   const int xblocks = (int)((pos + WAVES * 16 * NT - 1) / (WAVES * 16 * NT));
   a.rpw = convt_rows_per_wg(xblocks, a.s, 256, g_cand8_rpw.load(std::memory_order_relaxed));  // one workgroup per CU
-  up3_cand8_bf16_kernel<<<dim3(xblocks, a.s / a.rpw), WAVES * 64, LDS_BYTES, st>>>(a);
-  FLM_LAUNCH_CHECK("up3_cand8_bf16_kernel");
+  up3_cand8_kernel<BF><<<dim3(xblocks, a.s / a.rpw), WAVES * 64, LDS_BYTES, st>>>(a);
+  FLM_LAUNCH_CHECK("up3_cand8_kernel");
   return FLM_OK;
 }
 
@@ -1058,8 +1120,8 @@ int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub) {
   return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt) * sub;
 }
 
-// A/B knob (flm_set_tuning "bf16_cand8"): 1 (default) the 8-wave kernel above for the bf16 candidate launch, 0 the generic
-// kernel; same keys either way, so it never changes results or layouts
+// A/B knob (flm_set_tuning "up3_cand8"): bit 0 the 8-wave kernel above for the bf16 candidate launch, bit 1 for the fp32
+// one (default 1: in fp32 the two kernels take the same time, and the generic one stays on the headline path), 0 the generic kernel; same keys either way, so it never changes results or layouts
 static std::atomic<int> g_cand8{1};
 void convt_cand8_enable(int on) { g_cand8.store(on, std::memory_order_relaxed); }
 
@@ -1101,8 +1163,11 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
       set_error("convt: the candidate epilogue is built for strides that are multiples of 4");
       return FLM_ERR_UNSUPPORTED;
     }
-    if (d.g.bf16 && g_cand8.load(std::memory_order_relaxed) && (d.s & 3) == 0 && d.s >= 4 && (long long)d.s * d.s * cand8::SLOT_BYTES < 0x7fffffffll)
-      return launch_cand8(st, a);
+    const int c8 = g_cand8.load(std::memory_order_relaxed);  // bit 0: bf16, bit 1: fp32
+    if ((d.s & 3) == 0 && d.s >= 4 && (long long)d.s * d.s * cand8::Cfg<false>::PHASE_BYTES < 0x7fffffffll) {
+      if (d.g.bf16 && (c8 & 1)) return launch_cand8<true>(st, a);
+      if (!d.g.bf16 && (c8 & 2)) return launch_cand8<false>(st, a);
+    }
     return d.g.bf16 ? launch_t<5, 9, true, 2, 1, true>(st, a) : launch_t<5, 17, false, 1, 1, true>(st, a);
   }
   if (d.epilogue == 4) {

@@ -227,9 +227,10 @@ int flm_profile_filter(const char* layer);
  *                           registers, no LDS write pass); 0: global -> registers -> LDS
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
- *   "bf16_cand8"            1 (default): the bf16 candidate launch of the last transposed conv runs the 8-wave kernel
- *                           (csrc/flm_convt.hip, up3_cand8_bf16_kernel); 0: the generic kernel.  Same keys either way
- *   "bf16_cand8_rows"       phase rows one workgroup of that kernel walks with the same input fragments: 0 (default)
+ *   "up3_cand8"             bit 0 / bit 1: the bf16 / fp32 candidate launch of the last transposed conv runs the
+ *                           8-wave kernel (csrc/flm_convt.hip, up3_cand8_kernel); default 1 (bf16); 0: the generic kernel.
+ *                           Same keys either way
+ *   "up3_cand8_rows"        phase rows one workgroup of that kernel walks with the same input fragments: 0 (default)
  *                           chosen from the batch, else 1, 2, 4 or 8
  * The options that change the workspace layout ("landmark_candidates", "candidate_*") are per-call arguments:
  * flm_forward_opts above. */

@@ -46,6 +46,34 @@ def test_candidate_path_equals_materialised_decode(flm, weights68, dtype):
     assert (ref == -1).any() and (ref != -1).any()  # thresh 0.5 rejects part of the landmarks: both branches ran
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_eight_wave_kernel_equals_generic_kernel(flm, weights68, dtype):
+    """flm_set_tuning "up3_cand8": the 8-wave candidate kernel (bf16 by default, fp32 on request) against the generic
+    kernel and against the materialised decode, n = 4 and 25, a ragged batch (faces end inside a workgroup) and forced
+    rows per workgroup; also with lists shrunk until they overflow (the gated fallback must still give the exact result)."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    rng = np.random.default_rng(47)
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(rng.integers(0, 256, (9, 256, 256, 3), dtype=np.uint8)).cuda()
+    try:
+        for n_points in (4, 25):
+            ref = _landmarks(model, xd, n_points, 0.0, candidates=False)
+            for knob, rows in ((0, 0), (3, 0), (3, 1), (3, 8)):
+                _lib.check(lib.flm_set_tuning(b"up3_cand8", knob), "set_tuning")
+                _lib.check(lib.flm_set_tuning(b"up3_cand8_rows", rows), "set_tuning")
+                got = _landmarks(model, xd, n_points, 0.0, candidates=True)
+                assert np.array_equal(got, ref), (dtype, n_points, knob, rows)
+        _lib.check(lib.flm_set_tuning(b"up3_cand8", 3), "set_tuning")
+        got = _landmarks(model, xd, 4, 0.0, candidates=True, cap_div=4096)
+        assert np.array_equal(got, _landmarks(model, xd, 4, 0.0, candidates=False))
+    finally:
+        _lib.check(lib.flm_set_tuning(b"up3_cand8", 1), "set_tuning")
+        _lib.check(lib.flm_set_tuning(b"up3_cand8_rows", 0), "set_tuning")
+
+
 def test_candidate_overflow_falls_back(flm, weights68):
     """Lists 1/4096 of their size overflow in every face: the gated materialising launch must take over."""
     from flm_amd.networks import LANDMARKS_MODELS

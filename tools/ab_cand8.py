@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: A/B of the bf16 candidate launch of up3 (flm_set_tuning "bf16_cand8": 8-wave kernel vs generic kernel),
+"""Developer tool: A/B of the bf16 candidate launch of up3 (flm_set_tuning "up3_cand8": 8-wave kernel vs generic kernel),
 batch 512, per-layer HIP-event times and bit-equality of the landmarks."""
 import ctypes as C
 import os
@@ -23,8 +23,8 @@ out = {}
 ROWS = [int(v) for v in os.environ.get("ROWS", "0").split(",")]
 for npts in (4, 25):
     for knob, rows in [(0, 0)] + [(1, r) for r in ROWS] + [(0, 0)] + [(1, r) for r in ROWS]:
-        _lib.check(lib.flm_set_tuning(b"bf16_cand8", knob), "set_tuning")
-        _lib.check(lib.flm_set_tuning(b"bf16_cand8_rows", rows), "set_tuning")
+        _lib.check(lib.flm_set_tuning(b"up3_cand8", knob), "set_tuning")
+        _lib.check(lib.flm_set_tuning(b"up3_cand8_rows", rows), "set_tuning")
         for _ in range(3):
             lm = model.forward_device(x, "landmarks", n_points=npts)
         torch.cuda.synchronize()
