@@ -338,7 +338,10 @@ __global__ __launch_bounds__(256) void cand_merge_kernel(CandMergeArgs a) {
 
 static void decode_plan(int n, int h, int w, int* chunks, int* chunk_px) {
   const int HW = h * w;
-  int s = 2048 / (n > 0 ? n : 1);
+  // about 1536 workgroups per launch (6 per CU): fewer and the chip is short of loads in flight (1024: batch 512 at 4.5
+  // TB/s), more and the per-chunk fixed costs -- list set-up, the merge's inputs -- grow (2048: batch 64 at 2.9 TB/s
+  // instead of 3.3, batch 512 at 5.2 instead of 5.6; tools/bench_hbm.py)
+  int s = 1536 / (n > 0 ? n : 1);
   if (s < 1) s = 1;
   if (s > 32) s = 32;
   int px = (HW + s - 1) / s;

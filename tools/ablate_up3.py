@@ -26,6 +26,7 @@ _lib.LIB_PATH = %r
 from flm_amd.networks import LANDMARKS_MODELS
 from flm_amd.weights import synth_fcn8_weights
 lib = _lib.load()
+lib.flm_set_tuning(b"up3_cand8", int(os.environ.get("CAND8", "1")))
 B = int(os.environ.get("B", "512")); dt = os.environ.get("DTYPE", "bf16")
 model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dt)
 model.load_weights(synth_fcn8_weights(68, 2))
