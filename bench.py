@@ -431,6 +431,10 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="extra untimed warm-up before the timed region so a short region starts at settled clocks")
     ap.add_argument("--no-hbm-kernels", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend for N > 1: nccl (= RCCL, the measured configuration) or gloo (a dry "
+                         "run of the multi-rank flow on a box with fewer GPUs than ranks: ranks share devices, the "
+                         "gather goes through the host; its numbers mean nothing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -449,9 +453,12 @@ def main():
         raise SystemExit("--config 3 is the one-GPU bf16 run; use --config 4 for N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    ndev = torch.cuda.device_count()
+    if world > 1 and args.backend == "nccl" and ndev < world:
+        raise SystemExit("--gpus %d needs %d visible GPUs for RCCL, found %d" % (world, world, ndev))
+    torch.cuda.set_device(local_rank % ndev if world > 1 else 0)
     if world > 1:
-        distributed.init_process_group("nccl")
+        distributed.init_process_group(args.backend)
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.load()
 

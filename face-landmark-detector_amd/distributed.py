@@ -67,8 +67,14 @@ def all_gather_landmarks(local, total: int, group=None):
         send = torch.cat([local, pad], 0)
     else:
         send = local.contiguous()
-    out = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, send, group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # dry runs of the multi-rank flow without RCCL (ranks sharing a GPU): gloo gathers host tensors
+        host = torch.empty((world * mx,) + tail, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        out = host.to(local.device)
+    else:
+        out = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, send, group=group)
     if all(c == mx for c in counts):
         return out
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], 0)
