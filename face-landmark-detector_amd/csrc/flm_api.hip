@@ -235,8 +235,8 @@ int flm_set_tuning(const char* key, int value) {
     return FLM_ERR_ARG;
   }
   if (!strcmp(key, "up3_cand8")) {  // candidate launch of up3: bit 0 bf16, bit 1 fp32 take the 8-wave kernel (default 3)
-    if (value < 0 || value > 3) {
-      set_error("flm_set_tuning: up3_cand8 must be in [0,3]");
+    if (value < 0 || value > 7) {
+      set_error("flm_set_tuning: up3_cand8 must be in [0,7]");
       return FLM_ERR_ARG;
     }
     flm::convt_cand8_enable(value);

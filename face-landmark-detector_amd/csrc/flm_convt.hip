@@ -651,30 +651,32 @@ static int convt_rows_per_wg(int xblocks, int s, int wg_slots, int forced = 0) {
 // bf16 batch 512: 2.63 -> 2.12 ms.
 // =====================================================================================================================
 namespace cand8 {
-constexpr int MT = 5, WAVES = 8;
+constexpr int MT = 5;
 constexpr int PIECE = 1024;             // one (g, m) fragment tile: 64 lanes x 16 bytes
-constexpr int STEP_G = 9;               // k groups per ring step
-constexpr int SLOT_BYTES = STEP_G * MT * PIECE;  // 46,080 bytes: a ring step (bf16: a whole phase)
 constexpr int KEY_CAP = 512;            // keys a wave holds in LDS between flushes
-constexpr size_t LDS_BYTES = 2 * (size_t)SLOT_BYTES + (size_t)WAVES * KEY_CAP * 8;
+// WAVES waves per workgroup share a ring of two steps of STEP_G k groups: (8, 9) = one workgroup per CU, 45 KiB steps
+// (bf16: a whole phase); (4, 3) = two workgroups per CU that drift apart, 15 KiB steps, twice the weight traffic
+constexpr size_t lds_bytes(int waves, int step_g) { return 2 * (size_t)step_g * MT * PIECE + (size_t)waves * KEY_CAP * 8; }
 
 template <bool BF>
 struct Cfg {
   static constexpr int G = BF ? 9 : 17;      // k groups: 32 deep (bf16, one 16x16x32 MFMA) or 16 deep (fp32, four 16x16x4)
   static constexpr int NT = BF ? 2 : 1;      // pixel tiles of 16 per wave
   static constexpr int KM = BF ? 1 : 4;      // MFMAs per (k group, class tile, pixel tile)
-  static constexpr int NSTEP = (G + STEP_G - 1) / STEP_G;  // ring steps per phase
   static constexpr int PHASE_BYTES = G * MT * PIECE;
   static constexpr int NSLOT = G * 4 * NT * KM;            // MFMAs of the four common class tiles per phase and wave
   // ---- the epilogue of one phase as a list of small ops (pixel tiles interleaved: op k of a stage works on nt = k % NT)
   //   A  9 NT  running class maximum, two values per v_max3     B  NT  cross-lane-group maximum, -max*log2(e)
-  //   C 17 NT  e = exp(x - max)                                  D 17 NT  sum += e (the generic kernel's order)
+  //   C 17 NT (bf16: 34 NT, the fma and the v_exp_f32 of a value two ops apart)  e = exp(x - max)
+  //   D 17 NT  sum += e (the generic kernel's order)
   //   E    NT  cross-lane-group sum, reciprocal, pixel validity  F 17 NT  p = e * (1/sum)
   //   G  5 NT  p >= tau for the 4 (1) values of a class tile -> one bit per group
-  static constexpr int B0 = 9 * NT, C0 = B0 + NT, D0 = C0 + 17 * NT, E0 = D0 + 17 * NT, F0 = E0 + NT, G0 = F0 + 17 * NT,
+  static constexpr int CS = BF ? 2 : 1;  // ops per value in stage C
+  static constexpr int B0 = 9 * NT, C0 = B0 + NT, D0 = C0 + 17 * NT * CS, E0 = D0 + 17 * NT, F0 = E0 + NT, G0 = F0 + 17 * NT,
                        NOPS = G0 + 5 * NT;
   static constexpr int op_cost(int k) {  // issue cycles / 4, roughly (bf16: v_exp_f32 8; fp32: the accurate expf, a true division)
-    return k < B0 ? 1 : k < C0 ? 7 : k < D0 ? (BF ? 3 : 20) : k < E0 ? 1 : k < F0 ? (BF ? 8 : 16) : k < G0 ? 1 : 5;
+    return k < B0 ? 1 : k < C0 ? 7 : k < D0 ? (BF ? (((k - C0) % (2 * NT)) < NT ? 1 : 2) : 20) : k < E0 ? 1 : k < F0 ? (BF ? 8 : 16)
+                                                                                                  : k < G0 ? 1 : 5;
   }
 };
 template <bool BF>
@@ -718,11 +720,14 @@ __device__ __forceinline__ void dma_piece(dma_srd srd, unsigned lds_addr, unsign
 }
 }  // namespace cand8
 
-template <bool BF>
-__global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 waves = 2 per SIMD: 256 registers each
+template <bool BF, int WAVES, int STEP_G>
+__global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {  // 2 waves per SIMD: 256 registers each
   using namespace cand8;
   using C = Cfg<BF>;
-  constexpr int G = C::G, NT = C::NT, KM = C::KM, NSTEP = C::NSTEP, NOPS = C::NOPS;
+  constexpr int G = C::G, NT = C::NT, KM = C::KM, NOPS = C::NOPS;
+  constexpr int NSTEP = (G + STEP_G - 1) / STEP_G;          // ring steps per phase
+  constexpr int SLOT_BYTES = STEP_G * MT * PIECE;           // a ring step
+  constexpr int NDMA = (STEP_G * MT + WAVES - 1) / WAVES;   // pieces a wave requests per step
   if (a.gate && *a.gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef __attribute__((address_space(3))) char lds_char;
@@ -805,9 +810,9 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 
   // row0*s + t: consecutive rows are consecutive in the packed array).  Piece i -> (g, m): a leader phase (t % 4 == 0)
   // moves five class tiles per k group, a short one the four common ones.
   auto dma_issue = [&](int u, int i) __attribute__((always_inline)) {
-    const int t = NSTEP == 1 ? u : u >> 1, st = NSTEP == 1 ? 0 : u & 1;
+    const int t = u / NSTEP, st = u - t * NSTEP;
     const bool leader = (t & 3) == 0;
-    const int ng = st == 0 ? (G < STEP_G ? G : STEP_G) : G - STEP_G;
+    const int ng = (st + 1) * STEP_G <= G ? STEP_G : G - st * STEP_G;
     const int np = ng * (leader ? MT : 4);
     if (i < np) {
       const int pc = leader ? i : (i >> 2) * MT + (i & 3);  // piece of the step: (g - g0) * 5 + m
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 
     }
   };
 #pragma unroll
-  for (int k = 0; k < 6; ++k) dma_issue(0, wave + WAVES * k);
+  for (int k = 0; k < NDMA; ++k) dma_issue(0, wave + WAVES * k);
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
   __syncthreads();
 
@@ -872,10 +877,21 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 
       nmxl[nt] = -mx[nt] * 1.44269504088896340736f;
       FLM_PIN(nmxl[nt]);
     } else if constexpr (K < C::D0) {
-      constexpr int nt = (K - C::C0) % NT, i = (K - C::C0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
-      float v = softmax_exp<BF>(PV[nt][m][e], mx[nt], nmxl[nt]);
-      FLM_PIN(v);
-      PV[nt][m][e] = v;
+      if constexpr (BF) {
+        // the exponent's argument and the v_exp_f32 of a value are separate ops with the other pixel tile's in between:
+        // back to back, the dependent pair stalls the in-order wave (same two instructions as softmax_exp<true>)
+        constexpr int c = K - C::C0, i = c / (2 * NT), rr = c % (2 * NT), nt = rr % NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+        float v;
+        if constexpr (rr < NT) v = __builtin_fmaf(PV[nt][m][e], 1.44269504088896340736f, nmxl[nt]);
+        else v = __builtin_amdgcn_exp2f(PV[nt][m][e]);
+        FLM_PIN(v);
+        PV[nt][m][e] = v;
+      } else {
+        constexpr int nt = (K - C::C0) % NT, i = (K - C::C0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
+        float v = softmax_exp<BF>(PV[nt][m][e], mx[nt], nmxl[nt]);
+        FLM_PIN(v);
+        PV[nt][m][e] = v;
+      }
     } else if constexpr (K < C::E0) {
       constexpr int nt = (K - C::D0) % NT, i = (K - C::D0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
       if constexpr (i == 0) sum[nt] = 0.f + PV[nt][m][e];
@@ -1007,7 +1023,7 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 
       });
       // the next step's pieces: requested in the first slots -- its ring slot has been free since this step's barrier,
       // and the requests then have the whole step to land
-      if constexpr (IL < 6) {
+      if constexpr (IL < NDMA) {
         if (u + 1 < nph * NSTEP && !(FLM_ABLATE & 1024)) dma_issue(u + 1, wave + WAVES * IL);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1070,17 +1086,19 @@ __global__ __launch_bounds__(512, 2) void up3_cand8_kernel(ConvTArgs a) {  // 8 
 static std::atomic<int> g_cand8_rpw{0};  // A/B knob "up3_cand8_rows": 0 = automatic, else phase rows per workgroup (1, 2, 4, 8)
 void convt_cand8_rows(int rpw) { g_cand8_rpw.store(rpw, std::memory_order_relaxed); }
 
-template <bool BF>
+template <bool BF, int WAVES, int STEP_G>
 static int launch_cand8(hipStream_t st, ConvTArgs a) {
   using namespace cand8;
   constexpr int NT = Cfg<BF>::NT;
+  constexpr size_t lds = lds_bytes(WAVES, STEP_G);
+  static_assert(lds * (8 / WAVES) <= 160 * 1024, "cand8: LDS budget of a CU");
   static FuncAttrOnce attr;
-  FLM_FUNC_ATTR_ONCE(attr, (&up3_cand8_kernel<BF>), LDS_BYTES);
+  FLM_FUNC_ATTR_ONCE(attr, (&up3_cand8_kernel<BF, WAVES, STEP_G>), lds);
   a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 16 * NT) * 16 * NT;  // per-face padding at wave granularity
   const long long pos = (long long)a.n * a.ppf;
   const int xblocks = (int)((pos + WAVES * 16 * NT - 1) / (WAVES * 16 * NT));
-  a.rpw = convt_rows_per_wg(xblocks, a.s, 256, g_cand8_rpw.load(std::memory_order_relaxed));  // one workgroup per CU
-  up3_cand8_kernel<BF><<<dim3(xblocks, a.s / a.rpw), WAVES * 64, LDS_BYTES, st>>>(a);
+  a.rpw = convt_rows_per_wg(xblocks, a.s, 256 * (8 / WAVES), g_cand8_rpw.load(std::memory_order_relaxed));
+  up3_cand8_kernel<BF, WAVES, STEP_G><<<dim3(xblocks, a.s / a.rpw), WAVES * 64, lds, st>>>(a);
   FLM_LAUNCH_CHECK("up3_cand8_kernel");
   return FLM_OK;
 }
@@ -1163,10 +1181,10 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
       set_error("convt: the candidate epilogue is built for strides that are multiples of 4");
       return FLM_ERR_UNSUPPORTED;
     }
-    const int c8 = g_cand8.load(std::memory_order_relaxed);  // bit 0: bf16, bit 1: fp32
+    const int c8 = g_cand8.load(std::memory_order_relaxed);  // bit 0: bf16, bit 1: fp32, bit 2: the 4-wave shape
     if ((d.s & 3) == 0 && d.s >= 4 && (long long)d.s * d.s * cand8::Cfg<false>::PHASE_BYTES < 0x7fffffffll) {
-      if (d.g.bf16 && (c8 & 1)) return launch_cand8<true>(st, a);
-      if (!d.g.bf16 && (c8 & 2)) return launch_cand8<false>(st, a);
+      if (d.g.bf16 && (c8 & 1)) return (c8 & 4) ? launch_cand8<true, 4, 3>(st, a) : launch_cand8<true, 8, 9>(st, a);
+      if (!d.g.bf16 && (c8 & 2)) return (c8 & 4) ? launch_cand8<false, 4, 3>(st, a) : launch_cand8<false, 8, 9>(st, a);
     }
     return d.g.bf16 ? launch_t<5, 9, true, 2, 1, true>(st, a) : launch_t<5, 17, false, 1, 1, true>(st, a);
   }

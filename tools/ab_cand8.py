@@ -21,8 +21,9 @@ model.load_weights(synth_fcn8_weights(68, 2))
 x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
 out = {}
 ROWS = [int(v) for v in os.environ.get("ROWS", "0").split(",")]
+KNOBS = [int(v) for v in os.environ.get("KNOBS", "1").split(",")]   # up3_cand8 values: 1 = 8 waves, 5 = 4 waves x 2 workgroups
 for npts in (4, 25):
-    for knob, rows in [(0, 0)] + [(1, r) for r in ROWS] + [(0, 0)] + [(1, r) for r in ROWS]:
+    for knob, rows in ([(0, 0)] + [(k, r) for k in KNOBS for r in ROWS]) * 2:
         _lib.check(lib.flm_set_tuning(b"up3_cand8", knob), "set_tuning")
         _lib.check(lib.flm_set_tuning(b"up3_cand8_rows", rows), "set_tuning")
         for _ in range(3):
@@ -37,7 +38,7 @@ for npts in (4, 25):
         while lib.flm_profile_read(i, name, 32, C.byref(v)) == 0:
             ms.setdefault(name.value.decode(), []).append(v.value); i += 1
         lib.flm_profile_disable()
-        out[(npts, knob)] = lm.cpu().numpy()
+        out[(npts, min(knob, 1))] = lm.cpu().numpy()
         print("n_points %2d cand8=%d rows=%d: up3 %.3f ms  up3_sub %.3f  decode %.3f  fallback %.3f  total %.3f" %
               (npts, knob, rows, np.median(ms["up3"]), np.median(ms["up3_sub"]), np.median(ms["decode"]),
                np.median(ms.get("up3_fallback", [0])), sum(float(np.median(a)) for a in ms.values())), flush=True)
