@@ -289,9 +289,10 @@ def mfma_roofline(layer, kernel, ms, batch, peak, traffic_file, extra=None):
     return r
 
 
-def hbm_kernels(lib, dev):
+def hbm_kernels(lib, dev, only=None):
     """The HBM-bound kernels on their own (outside any timed region): standalone decode of materialised heatmaps and the
-    alignment warp, algorithmic bytes / mean launch duration / 8 TB/s."""
+    alignment warp, algorithmic bytes / mean launch duration / 8 TB/s.  `only`: restrict to the entries whose key is listed
+    (tools/bench_hbm.py under rocprofv3: one batch size per profiled run)."""
     import torch
     from flm_amd import alignment
     from flm_amd.utils.metrics import decode_device
@@ -309,6 +310,8 @@ def hbm_kernels(lib, dev):
         return e0.elapsed_time(e1) / reps
 
     for nb in (64, 512):
+        if only and "decode_top4_b%d" % nb not in only:
+            continue
         hm = torch.rand((nb, 264, 264, 68), dtype=torch.float32, device=dev)
         ms = timeit(lambda: decode_device(hm, 4, 0.0))
         gbs = DECODE_BYTES_PER_FACE * nb / ms / 1e6
@@ -319,6 +322,8 @@ def hbm_kernels(lib, dev):
                                        "traffic": load_traffic("traffic_latest.json", "decode_standalone_b%d" % nb)}
         del hm
     for nb in (64, 512):
+        if only and "warp_b%d" % nb not in only:
+            continue
         src = torch.randint(0, 256, (nb, 256, 256, 3), dtype=torch.uint8, device=dev)
         m = torch.tensor([[0.98, 0.05, 2.0], [-0.05, 0.98, 3.0]], dtype=torch.float32, device=dev).repeat(nb, 1, 1).contiguous()
         dst = torch.empty((nb, 256, 256, 3), dtype=torch.float32, device=dev)

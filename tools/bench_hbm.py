@@ -10,7 +10,8 @@ import bench  # noqa: E402
 import flm_amd  # noqa: E402,F401
 from flm_amd import _lib  # noqa: E402
 
-r = bench.hbm_kernels(_lib.load(), torch.device("cuda", 0))
+only = os.environ.get("ONLY")
+r = bench.hbm_kernels(_lib.load(), torch.device("cuda", 0), only.split(",") if only else None)
 for k, v in r.items():
     print("%-18s %.4f ms  %7.1f GB/s  %.3f of 8 TB/s" % (k, v["avg_launch_ms"], v["achieved"], v["frac"]))
 print(json.dumps(r))
