@@ -15,6 +15,10 @@ One step = one pass of the hot path over one batch of synthetic 256x256 uint8 BG
                       so one driver run per N measures both.
 --config 3            BASELINE.json configs[2]: 512 faces, bf16 operands / fp32 accumulate, one GPU, as the headline.
 --config 4            BASELINE.json configs[3]: 512 bf16 faces per GPU (4096 at 8) + all-gather, as the headline.
+--config 5            BASELINE.json configs[4]: 1080p multi-face stream -- per GPU 64 synthetic 1920x1080 frames with 1..16
+                      face boxes each (sides 96..400 px): box maths + crop + resize to 256x256 + landmarks + alignment,
+                      16 frames per launch sequence; one step = one pass over a rank's frames; frames are independent, no
+                      collective.  `value` is faces/s, `frames_per_s` rides along.
 Ranks are weak-scaled: every rank runs its own batch; the only collective is the landmark gather.  ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -236,6 +240,50 @@ class Workload:
         return step
 
 
+class StreamWorkload:
+    """BASELINE configs[4] on this rank: 1080p frames resident in HBM, 1..16 boxes per frame, `group` frames per launch
+    sequence (the detector that would supply the boxes does not exist in the reference, prediction.py:99,103)."""
+
+    def __init__(self, dtype, rank, n_points, n_frames=64, group=16):
+        import numpy as np
+        import torch
+        from flm_amd import _lib, alignment
+        from flm_amd.networks import LANDMARKS_MODELS
+        from flm_amd.weights import synth_fcn8_weights
+        self.dtype, self.n_points, self.group, self.n_frames = dtype, n_points, group, n_frames
+        self.dev = _lib.require_gpu()
+        self.model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
+        self.model.load_weights(synth_fcn8_weights(68, seed=2))
+        rng = np.random.default_rng(5 + rank)
+        self.frames = [torch.from_numpy(rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)).to(self.dev) for _ in range(8)]
+        self.faces = []
+        for _ in range(n_frames):
+            fb = []
+            for _ in range(int(rng.integers(1, 17))):
+                side = int(rng.integers(96, 401))
+                x0, y0 = int(rng.integers(0, 1920 - side)), int(rng.integers(0, 1080 - side))
+                fb.append((x0, y0, x0 + side, y0 + side))
+            self.faces.append(fb)
+        self.batch = sum(len(f) for f in self.faces)   # faces per step
+        self.tmpl = torch.from_numpy(alignment.canonical_template(68, 256, 256)).to(self.dev)
+        self.scale = (256 / self.model.output_width, 256 / self.model.output_height)
+
+    def make_step(self, world, total):
+        import torch
+        from flm_amd import alignment, prediction
+
+        def step():
+            lm = None
+            for f0 in range(0, self.n_frames, self.group):
+                crops = [prediction.crop_faces_device(self.frames[f % len(self.frames)], prediction.face_boxes(self.faces[f]),
+                                                      256, 256) for f in range(f0, min(f0 + self.group, self.n_frames))]
+                crops = torch.cat(crops, 0) if len(crops) > 1 else crops[0]
+                lm = self.model.forward_device(crops, "landmarks", n_points=self.n_points)
+                alignment.align_device(crops, lm, self.tmpl, 256, 256, self.scale)
+            return lm, None
+        return step
+
+
 def measure(lib, wl, steps, warmup, world, roof_layer, settle_s):
     """Timed region of one workload with the roofline kernel's launches bracketed by HIP events on the launch stream,
     then the per-layer pass.  Returns (seconds, roofline-layer ms, {layer: ms})."""
@@ -418,14 +466,46 @@ def bf16_side_object(lib, args, world, rank, tag):
     return obj, wl
 
 
+def stream_config(lib, args, rank, world, dev):
+    """--config 5: the stream as the headline line (no roofline block of its own: its launches have a different batch per
+    sequence; the kernels are the ones the other configurations price)."""
+    wl = StreamWorkload(args.stream_dtype, rank, args.n_points)
+    step = wl.make_step(world, 0)
+    dt, _ = timed_region(step, args.steps, args.warmup, world, dev, args.settle_ms / 1e3)
+    import torch
+    import torch.distributed as dist
+    faces = torch.tensor([wl.batch], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(faces)
+    coll = describe_collective(world, dev, 0, 68)
+    if rank == 0:
+        total = int(faces.item())
+        print(json.dumps({
+            "metric": "faces/sec (whole node), 1080p multi-face stream: box maths + crop/resize to 256x256 + FCN-8 landmarks "
+                      "(top-%d) + similarity/alignment warp" % args.n_points,
+            "value": total * args.steps / dt, "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.stream_dtype, "data": "synthetic",
+            "frames_per_s": wl.n_frames * world * args.steps / dt,
+            "config": {"workload": "BASELINE configs[4]: per GPU %d synthetic 1920x1080x3 uint8 frames resident in HBM, 1..16 "
+                                   "boxes each (sides 96..400 px, %d faces on rank 0), %d frames per launch sequence, "
+                                   "fcn_8(68) %s, decode top-%d, align to 256x256; no detector exists in the reference "
+                                   "(prediction.py:99,103): boxes are synthetic" % (wl.n_frames, wl.batch, wl.group,
+                                                                                    args.stream_dtype, args.n_points),
+                       "faces_per_step_all_ranks": total, "frames_per_gpu_per_step": wl.n_frames, "parallelism": "dp%d" % world,
+                       "collective": dict(coll, op="none (frames are independent; the device names were gathered)")},
+            "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="BASELINE.json configs[config-1] as the headline: 2 = 64 fp32 faces per GPU (default), 3 = 512 "
-                         "bf16 faces on one GPU, 4 = 512 bf16 faces per GPU + all-gather")
+                         "bf16 faces on one GPU, 4 = 512 bf16 faces per GPU + all-gather, 5 = the 1080p multi-face stream")
+    ap.add_argument("--stream-dtype", default="f32", choices=("f32", "bf16"), help="arithmetic of --config 5")
     ap.add_argument("--batch", type=int, default=0, help="faces per GPU per step (0 = the configuration's: 64 or 512)")
     ap.add_argument("--n-points", type=int, default=4)
     ap.add_argument("--cpu-faces", type=int, default=16, help="faces per repetition of the CPU baseline leg (0 = skip)")
@@ -467,6 +547,12 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.load()
 
+    if args.config == 5:
+        stream_config(lib, args, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     bf16_head = args.config in (3, 4)
     dtype = "bf16" if bf16_head else "f32"
     B = args.batch or (512 if bf16_head else 64)
