@@ -416,25 +416,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
           }
         }
       } else {
+        const int m_first = mbase + 4 * lh;
+        const int nn0 = MMAP == 2 ? m_first % a.n : 0, pos0 = MMAP == 2 ? m_first / a.n : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float u = fmaf(acc[i][j][r], sc, sh);
           if (a.ksplit > 1) {  // raw partial sums, stored in output row order
             if (cok && m < a.M) {
-              const size_t prow = (MMAP == 2) ? (size_t)(m % a.n) * (a.h * a.w) + m / a.n : (size_t)m;
+              const size_t prow = (MMAP == 2) ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
               a.part[((size_t)blockIdx.y * a.M + prow) * a.ldc + col] = acc[i][j][r];
             }
             continue;
           }
           if (cok && m < a.M) {
-            size_t orow;
-            if (MMAP == 2) {
-              const int nn = m % a.n, pos = m / a.n;
-              orow = (size_t)nn * (a.h * a.w) + pos;
-            } else {
-              orow = (size_t)m;
-            }
+            const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
             const size_t o = orow * a.ldc + col;
             if (MMAP == 0 && a.res) {  // residual add before the activation (ResNet bottlenecks)
               if (BF) u += (float)__builtin_bit_cast(__bf16, reinterpret_cast<const unsigned short*>(a.res)[o]);

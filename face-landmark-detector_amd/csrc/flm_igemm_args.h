@@ -57,6 +57,22 @@ __device__ __forceinline__ unsigned long long posmajor_posmask(int p, int h, int
   return mask;
 }
 
+// Output row (NHWC pixel index) of position-major GEMM row m = pos * n + face: face * (h*w) + pos.  The epilogues call it
+// for the 16 rows a lane holds of a 32-row accumulator tile -- offsets 0..27 from the lane's first row m_first, whose
+// (face, position) = (nn0, pos0) is divided ONCE: with n >= 32 a row wraps into the next position at most once.  (An
+// integer division per stored element, 128 per lane and tile, was a fifth of the bf16 fc6 launch.)
+__device__ __forceinline__ size_t posmajor_orow(int m, int m_first, int nn0, int pos0, int n, int hw) {
+  if (n >= 32) {
+    int nn = nn0 + (m - m_first), pos = pos0;
+    if (nn >= n) {
+      nn -= n;
+      ++pos;
+    }
+    return (size_t)nn * hw + pos;
+  }
+  return (size_t)(m % n) * hw + m / n;
+}
+
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 // bf16 layers whose tile grid fills the chip with 256-row tiles (flm_igemm_bf16.hip); returns 1 when it launched,

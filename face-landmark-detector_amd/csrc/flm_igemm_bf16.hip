@@ -419,18 +419,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
             }
           }
         } else {
+          const int m_first = mbase + 4 * lh;
+          const int nn0 = MMAP == 2 ? m_first % a.n : 0, pos0 = MMAP == 2 ? m_first / a.n : 0;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float u = fmaf(acc[i][j][r], sc, sh);
             if (cok && m < a.M) {
-              size_t orow;
-              if (MMAP == 2) {
-                const int nn = m % a.n, pos = m / a.n;
-                orow = (size_t)nn * (a.h * a.w) + pos;
-              } else {
-                orow = (size_t)m;
-              }
+              const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
               const size_t o = orow * a.ldc + col;
               if (RELU) u = fminf(fmaxf(u, 0.f), a.relu_max);
               if (!a.out_f32) reinterpret_cast<unsigned short*>(a.y)[o] = f2bf(u);
