@@ -75,6 +75,25 @@ __device__ __forceinline__ size_t posmajor_orow(int m, int m_first, int nn0, int
 
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
+// 4x4 transpose of bf16 values over a lane quad, for the epilogues of the 32x32 MFMA tiles: a lane holds four rows of
+// ONE column (2-byte stores, 64 B per row and instruction); afterwards lane q of the quad holds row q of the quad's
+// FOUR columns, 8 bytes it stores at once.  Two exchange steps on packed pairs: 16-bit halves with lane^1 (v_perm),
+// whole dwords with lane^2.  Every lane of the wave must be active.
+__device__ __forceinline__ uint2 quad_transpose_bf16(float r0, float r1, float r2, float r3, int q) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t));
+  const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t));
+  const unsigned o01 = (unsigned)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  const unsigned o23 = (unsigned)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xf, 0xf, true);
+  const unsigned sel = (q & 1) ? 0x03020706u : 0x05040100u;  // odd: (other.hi, own.hi); even: (own.lo, other.lo)
+  const unsigned t01 = __builtin_amdgcn_perm(o01, p01, sel);  // row q&1, the lane pair's two columns
+  const unsigned t23 = __builtin_amdgcn_perm(o23, p23, sel);  // row 2 + (q&1)
+  const bool low = q < 2;
+  const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(low ? t23 : t01), 0x4E, 0xf, 0xf, true);  // [2,3,0,1]
+  return make_uint2(low ? t01 : recv, low ? recv : t23);
+}
+
 // bf16 layers whose tile grid fills the chip with 256-row tiles (flm_igemm_bf16.hip); returns 1 when it launched,
 // 0 when the shape is left to the 128x128 kernel, < 0 on error.
 int launch_igemm_bf16_big(hipStream_t s, const IgemmArgs& a, int relu, int pool, int posmajor, int coutpad);
