@@ -36,6 +36,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 
 
+# per-source flags.  flm_enc1: the matrix results go to ordinary VGPRs -- the epilogue is the kernel's critical path and
+# would otherwise start with one v_accvgpr_read per accumulator register
+FILE_FLAGS = {"flm_enc1.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _hipcc() -> str:
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -46,6 +51,7 @@ def _hipcc() -> str:
 def _stamp(paths) -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     for p in sorted(paths):
         with open(p, "rb") as f:
             h.update(p.encode())
@@ -67,7 +73,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *extra_flags, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))

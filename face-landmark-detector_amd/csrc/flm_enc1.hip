@@ -182,6 +182,43 @@ __host__ __device__ inline int enc1_bf16_halo_stride(int w) {
   return need + ((16 - need % 32) + 32) % 32;
 }
 
+typedef float f32x2_e1 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_e1 __attribute__((ext_vector_type(2)));
+
+// Epilogue of one strip of 32 pooled pixels: BN + ReLU (+ 2x2 max) on the lane's 2 x 16 accumulators, channel pairs
+// stored as dwords.  Written for the instruction count -- the kernel streams 1 GB of f1 per 512 faces and its VALU
+// work, not the matrix pipe, sets the pace: register pairs through v_pk_fma_f32, v_max3, one v_cvt_pk_bf16_f32 per
+// stored dword, one base address per strip (the four pixel pairs of a lane are 256 bytes apart), and no bounds test
+// when the row is whole strips (FULL).  `dst` points at the lane's dword of the strip's first pixel pair.
+template <bool POOL, bool FULL>
+__device__ __forceinline__ void enc1_bf16_store_strip(const f32x16 (&acc)[2], const float (&sc)[2], const float (&sh)[2],
+                                                      unsigned int* __restrict__ dst, int xp, int wp, int w) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x2_e1 u[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        u[j][e] = __builtin_elementwise_fma((f32x2_e1){acc[j][4 * g + 2 * e], acc[j][4 * g + 2 * e + 1]},
+                                            (f32x2_e1){sc[j], sc[j]}, (f32x2_e1){sh[j], sh[j]});
+    if (POOL) {
+      const float v0 = fmaxf(fmaxf(fmaxf(fmaxf(u[0][0].x, 0.f), u[0][0].y), u[0][1].x), u[0][1].y);  // two v_max3
+      const float v1 = fmaxf(fmaxf(fmaxf(fmaxf(u[1][0].x, 0.f), u[1][0].y), u[1][1].x), u[1][1].y);
+      const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_e1){v0, v1}, bf16x2_e1));
+      if (FULL || xp + 2 * g < wp) dst[g * 64] = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = fmaxf(0.f, u[0][e >> 1][e & 1]), v1 = fmaxf(0.f, u[1][e >> 1][e & 1]);
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_e1){v0, v1}, bf16x2_e1));
+        // conv pixel (2*yp + (e>>1), 2*xp + (e&1)) of the lane's quad; dst = its (2*yp, 2*xp) pixel
+        if (FULL || xp + 2 * g < wp) dst[g * 128 + (e >> 1) * w * 32 + (e & 1) * 32] = pk;
+      }
+    }
+  }
+}
+
 constexpr int kEnc1RowsPerWg = 4;  // pooled rows per workgroup: the filter fragments (36 loads per lane) are built once
 
 template <bool U8, bool POOL>
@@ -297,31 +334,11 @@ __global__ __launch_bounds__(256) void enc1_bf16_kernel(const void* __restrict__
         for (int j = 0; j < 2; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[ky][j], acc[j], 0, 0, 0);
       }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int xp = xp0 + 8 * wave + 2 * g + lh;
-        if (POOL) {
-          float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v0 = fmaxf(v0, fmaf(acc[0][4 * g + e], sc[0], sh[0]));
-            v1 = fmaxf(v1, fmaf(acc[1][4 * g + e], sc[1], sh[1]));
-          }
-          const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v0) |
-                              ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v1) << 16);
-          if (xp < wp) f1w[(((size_t)img * hp + yp) * wp + xp) * 32 + lr] = pk;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v0 = fmaxf(0.f, fmaf(acc[0][4 * g + e], sc[0], sh[0]));
-            const float v1 = fmaxf(0.f, fmaf(acc[1][4 * g + e], sc[1], sh[1]));
-            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v0) |
-                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v1) << 16);
-            const int y = 2 * yp + (e >> 1), xx = 2 * xp + (e & 1);
-            if (xp < wp) f1w[(((size_t)img * h + y) * w + xx) * 32 + lr] = pk;
-          }
-        }
-      }
+      const int xp = xp0 + 8 * wave + lh;  // pooled pixel of accumulator group g: xp + 2*g
+      unsigned int* dst = POOL ? f1w + (((size_t)img * hp + yp) * wp + xp) * 32 + lr
+                               : f1w + (((size_t)img * h + 2 * yp) * w + 2 * xp) * 32 + lr;
+      if ((wp & 31) == 0) enc1_bf16_store_strip<POOL, true>(acc, sc, sh, dst, xp, wp, w);
+      else enc1_bf16_store_strip<POOL, false>(acc, sc, sh, dst, xp, wp, w);
     }
   }
 }

@@ -16,10 +16,19 @@ CSRC = os.path.join(ROOT, "face-landmark-detector_amd", "csrc")
 SOURCES = ["flm_igemm.hip", "flm_igemm_bf16.hip", "flm_conv3_halo.hip", "flm_convt.hip", "flm_enc1.hip", "flm_decode.hip", "flm_misc.hip", "flm_pack.hip", "flm_mobile.hip"]
 
 
+def _file_flags(src):
+    """The per-source flags of the real build (face-landmark-detector_amd/build.py: FILE_FLAGS)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_flm_build", os.path.join(ROOT, "face-landmark-detector_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return list(mod.FILE_FLAGS.get(src, []))
+
+
 def _asm_metadata(src, tmp):
     out = os.path.join(tmp, src + ".s")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
-           "-I", CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", *_file_flags(src),
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     text = open(out).read()
