@@ -168,8 +168,9 @@ __global__ __launch_bounds__(256) void enc1_kernel(const void* __restrict__ xin,
 // ---- bf16 variant (BASELINE configs[2]) ----------------------------------------------------------------
 // Same layer on v_mfma_f32_32x32x16_bf16: the fp32 kernel above spends 0.9 ms of matrix time per 512 faces on
 // a layer that is 1.3 % of the network's FLOPs; in bf16 it is a streaming kernel.
-//   * one workgroup = one pooled output row of one face; the whole 4-row halo of that row is staged once, as
-//     bf16 pixels padded to 4 channels (8 bytes), preprocess fused (x - mean in fp32, then one rounding);
+//   * one workgroup = kEnc1RowsPerWg pooled output rows of one face; the image rows they read pass through a
+//     four-row ring in LDS as bf16 pixels padded to 4 channels (8 bytes), preprocess fused (x - mean in fp32, then
+//     one rounding);
 //   * K = 3 filter rows x 16: k = 16*ky + 4*kx + c with kx = 3 and c = 3 carrying zero weights, so the
 //     fragment of lane (row, half) for filter row ky is the 16 bytes of halo pixels x+2*half, x+2*half+1:
 //     two ds_read_b64 (x may be odd), no gather arithmetic; 3 MFMAs per 32x32 tile;
@@ -219,7 +220,8 @@ __device__ __forceinline__ void enc1_bf16_store_strip(const f32x16 (&acc)[2], co
   }
 }
 
-constexpr int kEnc1RowsPerWg = 4;  // pooled rows per workgroup: the filter fragments (36 loads per lane) are built once
+constexpr int kEnc1RowsPerWg = 8;  // pooled rows per workgroup: the filter fragments (36 loads per lane) are built once, and
+                                   // 18 image rows are fetched for 16 (the two above the first pooled row a second time)
 
 template <bool U8, bool POOL>
 __global__ __launch_bounds__(256) void enc1_bf16_kernel(const void* __restrict__ xin, const float* __restrict__ w1p,
@@ -261,62 +263,79 @@ __global__ __launch_bounds__(256) void enc1_bf16_kernel(const void* __restrict__
   const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
   unsigned int* f1w = reinterpret_cast<unsigned int*>(f1);  // channel pairs
 
-  for (int yp = yp_first; yp < yp_first + kEnc1RowsPerWg && yp < hp; ++yp) {
-    if (yp != yp_first) __syncthreads();  // the previous row's fragment reads are done
-    // ---- stage the halo: rows 2yp-1..2yp+2, halo column c <-> input column c-1 ------------------------------
-    if (U8 && (w & 3) == 0) {
-      // 4 pixels = 12 bytes = 3 aligned dwords per thread and step
-      const int gpr = w >> 2;  // groups per row
-      for (int e = tid; e < 4 * gpr; e += 256) {
-        const int hr = e / gpr, g = e % gpr;
-        const int iy = 2 * yp - 1 + hr;
-        unsigned d0 = 0, d1 = 0, d2 = 0;
-        const bool ok = (unsigned)iy < (unsigned)h;
-        if (ok) {
-          const unsigned int* p = reinterpret_cast<const unsigned int*>(reinterpret_cast<const uint8_t*>(xin) +
-                                                                        (((size_t)img * h + iy) * w + 4 * g) * 3);
-          d0 = p[0]; d1 = p[1]; d2 = p[2];
-        }
-        const unsigned by[12] = {d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, d0 >> 24, d1 & 255, (d1 >> 8) & 255,
-                                 (d1 >> 16) & 255, d1 >> 24, d2 & 255, (d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-          if (ok) {
-            v[0] = (__bf16)((float)by[3 * k + 2] - mean_rgb[0]);
-            v[1] = (__bf16)((float)by[3 * k + 1] - mean_rgb[1]);
-            v[2] = (__bf16)((float)by[3 * k + 0] - mean_rgb[2]);
-          }
-          halo[hr * hs + 4 * g + k + 1] = __builtin_bit_cast(uint2, v);
-        }
-      }
-      // zero borders: column 0 and columns w+1 .. hs-1
-      const int nz = hs - w;
-      for (int e = tid; e < 4 * nz; e += 256) {
-        const int hr = e / nz, z = e % nz;
-        halo[hr * hs + (z == 0 ? 0 : w + z)] = make_uint2(0u, 0u);
+  // ---- the halo is a ring of four image rows: row iy lives in slot (iy + 1) & 3.  A pooled row reads rows 2yp-1..2yp+2;
+  //      the next one keeps two of them and replaces the other two, so every image row is fetched and converted once per
+  //      workgroup (plus the two rows above its first pooled row).  The two new rows are requested BEFORE the strips of
+  //      the current pooled row are computed and written to LDS after them: their latency hides behind the matrix work.
+  //      Halo column c <-> input column c-1; column 0 and columns w+1.. stay zero (written once).
+  const uint8_t* xu8 = reinterpret_cast<const uint8_t*>(xin);
+  const float* xf32 = reinterpret_cast<const float*>(xin);
+  const int gpr = w >> 2;                                 // groups of 4 pixels (12 bytes = 3 aligned dwords) per row
+  const bool quads = U8 && (w & 3) == 0;                  // the dword path
+  const bool prefetch = quads && 2 * gpr <= 256;          // one group per thread covers both new rows
+  auto px_u8 = [&](unsigned b, unsigned g_, unsigned r_) {  // BGR bytes -> RGB - mean, 4 bf16 (one rounding)
+    bf16x4 v = {(__bf16)((float)r_ - mean_rgb[0]), (__bf16)((float)g_ - mean_rgb[1]), (__bf16)((float)b - mean_rgb[2]), (__bf16)0.f};
+    return __builtin_bit_cast(uint2, v);
+  };
+  auto quad_load = [&](int iy, int g, unsigned (&d)[3]) {
+    d[0] = d[1] = d[2] = 0u;
+    if ((unsigned)iy < (unsigned)h) {
+      const unsigned int* p = reinterpret_cast<const unsigned int*>(xu8 + (((size_t)img * h + iy) * w + 4 * g) * 3);
+      d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+    }
+  };
+  auto quad_store = [&](int iy, int g, const unsigned (&d)[3]) {
+    uint2* o = halo + ((iy + 1) & 3) * hs + 4 * g + 1;
+    if ((unsigned)iy < (unsigned)h) {
+      o[0] = px_u8(d[0] & 255, (d[0] >> 8) & 255, (d[0] >> 16) & 255);
+      o[1] = px_u8(d[0] >> 24, d[1] & 255, (d[1] >> 8) & 255);
+      o[2] = px_u8((d[1] >> 16) & 255, d[1] >> 24, d[2] & 255);
+      o[3] = px_u8((d[2] >> 8) & 255, (d[2] >> 16) & 255, d[2] >> 24);
+    } else {
+      o[0] = o[1] = o[2] = o[3] = make_uint2(0u, 0u);  // rows above / below the image
+    }
+  };
+  auto stage_two_rows = [&](int iy0) {  // rows iy0, iy0 + 1, synchronously
+    if (quads) {
+      for (int e = tid; e < 2 * gpr; e += 256) {
+        const int hr = e >= gpr, g = e - hr * gpr;
+        unsigned d[3];
+        quad_load(iy0 + hr, g, d);
+        quad_store(iy0 + hr, g, d);
       }
     } else {
-      for (int e = tid; e < 4 * hs; e += 256) {
-        const int hr = e / hs, hc = e % hs;
-        const int iy = 2 * yp - 1 + hr, ix = hc - 1;
-        bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) {
-          const size_t pix = ((size_t)img * h + iy) * w + ix;
-          if (U8) {
-            const uint8_t* p = reinterpret_cast<const uint8_t*>(xin) + pix * 3;
-            v[0] = (__bf16)((float)p[2] - mean_rgb[0]);
-            v[1] = (__bf16)((float)p[1] - mean_rgb[1]);
-            v[2] = (__bf16)((float)p[0] - mean_rgb[2]);
-          } else {
-            const float* p = reinterpret_cast<const float*>(xin) + pix * 3;
-            v[0] = (__bf16)p[0]; v[1] = (__bf16)p[1]; v[2] = (__bf16)p[2];
+      for (int hr = 0; hr < 2; ++hr) {
+        const int iy = iy0 + hr;
+        uint2* o = halo + ((iy + 1) & 3) * hs + 1;
+        for (int ix = tid; ix < w; ix += 256) {
+          bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if ((unsigned)iy < (unsigned)h) {
+            const size_t pix = ((size_t)img * h + iy) * w + ix;
+            if (U8) {
+              o[ix] = px_u8(xu8[pix * 3], xu8[pix * 3 + 1], xu8[pix * 3 + 2]);
+              continue;
+            }
+            v[0] = (__bf16)xf32[pix * 3]; v[1] = (__bf16)xf32[pix * 3 + 1]; v[2] = (__bf16)xf32[pix * 3 + 2];
           }
+          o[ix] = __builtin_bit_cast(uint2, v);
         }
-        halo[e] = __builtin_bit_cast(uint2, v);
       }
     }
-    __syncthreads();
+  };
+  for (int hr = 0; hr < 4; ++hr) {  // zero borders of the four slots
+    for (int z = tid; z < hs - w; z += 256) halo[hr * hs + (z == 0 ? 0 : w + z)] = make_uint2(0u, 0u);
+  }
+  stage_two_rows(2 * yp_first - 1);
+  stage_two_rows(2 * yp_first + 1);
+  __syncthreads();
+  const int yp_end = min(yp_first + kEnc1RowsPerWg, hp);
+  const int pf_hr = tid >= gpr, pf_g = tid - pf_hr * gpr;  // this thread's group of the two new rows (prefetch form)
+
+  for (int yp = yp_first; yp < yp_end; ++yp) {
+    const bool more = yp + 1 < yp_end;
+    unsigned pf[3] = {0u, 0u, 0u};
+    if (more && prefetch && tid < 2 * gpr) quad_load(2 * yp + 3 + pf_hr, pf_g, pf);
+    const int slot0 = 2 * yp + dy;  // slot of filter row ky: (slot0 + ky) & 3
 
     for (int xp0 = 0; xp0 < wp; xp0 += 32) {
       const int x = 2 * (xp0 + q) + dx;  // conv column; halo columns x..x+3
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(256) void enc1_bf16_kernel(const void* __restrict__
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        const uint2* hp_ = halo + (dy + ky) * hs + x + 2 * lh;
+        const uint2* hp_ = halo + ((slot0 + ky) & 3) * hs + x + 2 * lh;
         const uint2 p0 = hp_[0], p1 = hp_[1];
         const uint4 av = make_uint4(p0.x, p0.y, p1.x, p1.y);
 #pragma unroll
@@ -339,6 +358,15 @@ __global__ __launch_bounds__(256) void enc1_bf16_kernel(const void* __restrict__
                                : f1w + (((size_t)img * h + 2 * yp) * w + 2 * xp) * 32 + lr;
       if ((wp & 31) == 0) enc1_bf16_store_strip<POOL, true>(acc, sc, sh, dst, xp, wp, w);
       else enc1_bf16_store_strip<POOL, false>(acc, sc, sh, dst, xp, wp, w);
+    }
+    if (more) {
+      __syncthreads();  // every wave has read the two rows that leave the ring
+      if (prefetch) {
+        if (tid < 2 * gpr) quad_store(2 * yp + 3 + pf_hr, pf_g, pf);
+      } else {
+        stage_two_rows(2 * yp + 3);
+      }
+      __syncthreads();
     }
   }
 }
