@@ -459,7 +459,7 @@ def bf16_side_object(lib, args, world, rank, tag):
                        "the headline%s" % (tag, wl.batch, world, " + all-gather of the landmarks" if world > 1 else ""),
            "dtype": "bf16", "n_gpus": world, "faces_per_s": total * steps / dt, "ms_per_step": 1e3 * dt / steps,
            "steps": steps,
-           "roofline": mfma_roofline("up3", "convt_kernel<5,9,bf16,...> (up3: Conv2DTranspose 16x16 s8 68->68 on 32x32, "
+           "roofline": mfma_roofline("up3", "up3_cand8_kernel<bf16, 8 waves> (up3: Conv2DTranspose 16x16 s8 68->68 on 32x32, "
                                      "softmax + candidate keys in the epilogue)", up3_ms, wl.batch, PEAK_BF16_TFLOPS,
                                      "traffic_bf16_latest.json"),
            "forward": fwd}
@@ -583,7 +583,7 @@ def main():
         value = total * args.steps / dt
         names = {2: "BASELINE configs[1]", 3: "BASELINE configs[2]", 4: "BASELINE configs[3]"}
         if bf16_head:
-            roof = mfma_roofline("up3", "convt_kernel<5,9,bf16,...> (up3 + softmax + candidate keys)", roof_ms, B, peak,
+            roof = mfma_roofline("up3", "up3_cand8_kernel<bf16, 8 waves> (up3 + softmax + candidate keys)", roof_ms, B, peak,
                                  "traffic_bf16_latest.json")
         else:
             issued = fc6_issued_gflop(B)

@@ -37,7 +37,7 @@ def layer_f32(name, grid):
         return "decode"
     if "cand_tau" in name:
         return "tau"
-    if "warp_kernel" in name:
+    if "warp_kernel" in name or "warp_u8_kernel" in name:
         return "warp"
     if "similarity" in name:
         return "similarity"
@@ -78,7 +78,7 @@ def layer_bf16(name, grid):
         return "decode"
     if "cand_tau" in name:
         return "tau"
-    if "warp_kernel" in name:
+    if "warp_kernel" in name or "warp_u8_kernel" in name:
         return "warp"
     return None
 
@@ -89,9 +89,28 @@ def layer_hbm(name, grid):
         # of this table mix the two, so no traffic entry is derived for the standalone decode (round 1 measured it on
         # its own: 1.218 GB per batch-64 launch against 1.213 GB algorithmic)
         return None
-    if "warp_kernel" in name:
-        return "warp_b64" if grid <= 64 * 256 * 256 else "warp_b512"
+    if "warp_kernel" in name or "warp_u8_kernel" in name:
+        # warp_u8_kernel<4> runs a thread per 4 output pixels: 64 faces = 1,048,576 threads
+        return "warp_b64" if grid <= 64 * 256 * 256 // 4 else "warp_b512"
     return None
+
+
+def standalone_decode_traffic(base):
+    """tools/dec_traffic.sh: the standalone decode alone, one batch size per profiled run ->
+    {decode_standalone_b<N>: HBM-side bytes per decode (all its launches)}."""
+    out = {}
+    for b in (64, 512):
+        f, w = find(os.path.join(base, "b%d" % b, "FETCH_SIZE")), find(os.path.join(base, "b%d" % b, "WRITE_SIZE"))
+        if not f or not w:
+            continue
+        fl, wl = load(f), load(w)
+        tot = 0.0
+        for key, v in fl.items():
+            if "flm::decode_" in key[0]:
+                tot += 2 * v.get("FETCH_SIZE", 0.0) * 1024 + wl.get(key, {}).get("WRITE_SIZE", 0.0) * 1024
+        if tot:
+            out["decode_standalone_b%d" % b] = int(tot)
+    return out
 
 
 def report(base, tag, suffix, layer_of, traffic_file, merge=False):
@@ -144,6 +163,14 @@ def main():
     report(os.path.join(base, "f32"), tag, "", layer_f32, "traffic_latest.json")
     report(os.path.join(base, "hbm"), tag, "_hbm", layer_hbm, "traffic_latest.json", merge=True)
     report(os.path.join(base, "bf16"), tag, "_bf16", layer_bf16, "traffic_bf16_latest.json")
+    dec = standalone_decode_traffic(os.path.join(os.path.dirname(os.path.abspath(base)), "dec_traffic"))
+    if dec:
+        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        cur = json.load(open(tf))
+        cur.update(dec)
+        with open(tf, "w") as fh:
+            json.dump(cur, fh, indent=1, sort_keys=True)
+        print("standalone decode", dec)
     for sub, out in (("stats", "%s_bench_kernel_stats.csv"), ("stats_bf16", "%s_bf16_kernel_stats.csv"),
                      ("stats_hbm", "%s_hbm_kernel_stats.csv")):
         hits = glob.glob(os.path.join(base, sub, "**", "*kernel_stats.csv"), recursive=True)
