@@ -282,51 +282,104 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
 }
 
 // Exact top n of a face's candidate keys (flm_convt.hip, epilogue 3): key = order_bits(p) << 32 | class << 17 |
-// pixel.  grid = (4, faces): workgroup g owns classes 17g .. 17g+16, wave w of it the classes 17g + w + 4k; every
-// wave streams all keys of the face (L2-resident, 64 per step) and feeds the ones of its classes to the same
-// descending (value, pixel) lists as the decode of a materialised map, so ties resolve identically.
+// pixel, in the order the workgroups of the candidate launch flushed them.  grid = (G, faces): workgroup g owns the
+// classes g*cpg .. g*cpg + cpg - 1, wave w of its NW the classes g*cpg + w + NW*k.  The keys are first BUCKETED by class in
+// LDS (counting sort: histogram, prefix, scatter; kMergeKeys per pass, a longer list takes several passes with the
+// lists kept in registers), then every wave feeds only the ~cnt/68 keys of each of its classes to the same descending
+// (value, pixel) lists as the decode of a materialised map, so ties resolve identically -- the keys are distinct and
+// the lists order-independent, so the bucket order does not matter.  (Round 1 had every wave scan ALL keys of the face
+// once per class it owned: 0.16 ms per 512 faces, a serial chain of cnt/64 steps x 5 classes per wave.)
 struct CandMergeArgs {
   const unsigned long long* cand;
   unsigned* cand_cnt;  // [n] fill counts, [n] = fallback flag
   int n, w, l, n_points, cap;
   float thresh;
   double* out;
+  int cpg;  // classes per workgroup
 };
 
-// CPW classes per wave: 5 (a workgroup of four waves covers 17 classes + 3 spare slots, 4 workgroups per face) when
-// the batch fills the chip anyway; 1 (17 workgroups per face) for small batches, where the scan is a serial chain of
-// cnt/64 steps per wave and four workgroups per face leave the chip empty -- every wave still streams all keys of its
-// face, so the finer split multiplies the L2 reads by four: it is chosen only below kCandFineBatch faces (64 faces:
-// 78 -> 56 us; at 512 the coarse split's 0.17 ms would become about 0.4 ms of L2 reads).
-constexpr int kCandFineBatch = 128;
+constexpr int kMergeKeys = 6144;     // 48 KiB of keys per pass: three workgroups per CU
+constexpr int kCandFineBatch = 128;  // below: four workgroups per face (the chip would sit empty with one)
 
-template <int CPW>
-__global__ __launch_bounds__(256) void cand_merge_kernel(CandMergeArgs a) {
+template <int CPW, int NW>  // NW waves, CPW = ceil(cpg / NW) classes per wave
+__global__ __launch_bounds__(NW * 64) void cand_merge_kernel(CandMergeArgs a) {
+  __shared__ unsigned long long keys[kMergeKeys];
+  __shared__ int hist[NW * CPW + 1], off[NW * CPW + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int face = blockIdx.y;
-  constexpr int CPG = CPW == 1 ? 4 : 17;  // classes per workgroup
-  const int cfirst = CPG * blockIdx.x, cend = min(cfirst + CPG, a.l);
+  const int cfirst = a.cpg * blockIdx.x, cend = min(cfirst + a.cpg, a.l);
+  const int nc = cend - cfirst;
   const unsigned cnt = min(a.cand_cnt[face], (unsigned)a.cap);
   const unsigned long long* src = a.cand + (size_t)face * a.cap;
   unsigned long long list[CPW], tau[CPW];
 #pragma unroll
   for (int k = 0; k < CPW; ++k) { list[k] = 0ull; tau[k] = 0ull; }
-  for (unsigned i0 = 0; i0 < cnt; i0 += 64) {
-    const unsigned long long key = (i0 + lane < cnt) ? src[i0 + lane] : 0ull;
-    const int cls = (int)((key >> 17) & 127u);
-    const unsigned long long stripped = (key & 0xffffffff00000000ull) | (key & 0x1ffffull);
+  constexpr int KPT = kMergeKeys / (NW * 64);  // keys per thread and pass, all loads in flight at once
+  for (unsigned base = 0; base < cnt; base += kMergeKeys) {
+    unsigned long long kreg[KPT];
 #pragma unroll
-    for (int k = 0; k < CPW; ++k) {
-      const int c = cfirst + wave + 4 * k;
-      if (c < cend) {  // wave-uniform
-        const unsigned long long cand = (key != 0ull && cls == c) ? stripped : 0ull;
-        if (__any(cand > tau[k])) insert_candidates(list[k], tau[k], cand, a.n_points, lane);
+    for (int j = 0; j < KPT; ++j) {
+      const unsigned i = base + tid + NW * 64 * j;
+      kreg[j] = i < cnt ? src[i] : 0ull;
+    }
+    if (tid <= NW * CPW) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int rel = (int)((kreg[j] >> 17) & 127u) - cfirst;
+      if (kreg[j] != 0ull && (unsigned)rel < (unsigned)nc) atomicAdd(&hist[rel], 1);
+      else kreg[j] = 0ull;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive prefix over the classes; hist becomes the write cursor
+      const int v = lane < nc ? hist[lane] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (lane < nc) {
+        off[lane] = incl - v;
+        hist[lane] = incl - v;
+      }
+      if (lane == 63 && nc >= 64) {
+        int run = incl;
+        for (int c = 64; c < nc; ++c) {
+          off[c] = run;
+          const int h = hist[c];
+          hist[c] = run;
+          run += h;
+        }
+        off[nc] = run;
+      }
+      if (nc < 64 && lane == nc) off[nc] = incl;  // (incl of lane nc = the total: its own v is 0)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      if (kreg[j] != 0ull) {
+        const int rel = (int)((kreg[j] >> 17) & 127u) - cfirst;
+        keys[atomicAdd(&hist[rel], 1)] = (kreg[j] & 0xffffffff00000000ull) | (kreg[j] & 0x1ffffull);
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const int rel = wave + NW * k;
+      if (rel < nc) {  // wave-uniform
+        const int lo = off[rel], hi = off[rel + 1];
+        for (int i0 = lo; i0 < hi; i0 += 64) {
+          const unsigned long long cand = (i0 + lane < hi) ? keys[i0 + lane] : 0ull;
+          if (__any(cand > tau[k])) insert_candidates(list[k], tau[k], cand, a.n_points, lane);
+        }
+      }
+    }
+    __syncthreads();  // the next pass overwrites the buckets
   }
 #pragma unroll
   for (int k = 0; k < CPW; ++k) {
-    const int c = cfirst + wave + 4 * k;
+    const int c = cfirst + wave + NW * k;
     if (c < cend) {
       // fewer than n keys: the threshold did not have n pixels above it (or the class has fewer than n non-zero
       // pixels), so the list may not hold the whole top n -> let the materialising path redo the batch
@@ -397,8 +450,13 @@ int launch_cand_merge(hipStream_t s, const unsigned long long* cand, unsigned* c
   CandMergeArgs a;
   a.cand = cand; a.cand_cnt = cand_cnt; a.n = n; a.w = w; a.l = l; a.n_points = n_points; a.cap = cap;
   a.thresh = thresh; a.out = out;
-  if (n < kCandFineBatch) cand_merge_kernel<1><<<dim3(17, n), 256, 0, s>>>(a);
-  else cand_merge_kernel<5><<<dim3(4, n), 256, 0, s>>>(a);
+  if (n < kCandFineBatch) {
+    a.cpg = 17;
+    cand_merge_kernel<5, 4><<<dim3(cdiv(l, 17), n), 256, 0, s>>>(a);
+  } else {
+    a.cpg = 68;
+    cand_merge_kernel<9, 8><<<dim3(1, n), 512, 0, s>>>(a);
+  }
   FLM_LAUNCH_CHECK("cand_merge_kernel");
   return FLM_OK;
 }
