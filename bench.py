@@ -244,7 +244,7 @@ class StreamWorkload:
     """BASELINE configs[4] on this rank: 1080p frames resident in HBM, 1..16 boxes per frame, `group` frames per launch
     sequence (the detector that would supply the boxes does not exist in the reference, prediction.py:99,103)."""
 
-    def __init__(self, dtype, rank, n_points, n_frames=64, group=16):
+    def __init__(self, dtype, rank, n_points, n_frames=64, group=64):
         import numpy as np
         import torch
         from flm_amd import _lib, alignment
@@ -275,9 +275,9 @@ class StreamWorkload:
         def step():
             lm = None
             for f0 in range(0, self.n_frames, self.group):
-                crops = [prediction.crop_faces_device(self.frames[f % len(self.frames)], prediction.face_boxes(self.faces[f]),
-                                                      256, 256) for f in range(f0, min(f0 + self.group, self.n_frames))]
-                crops = torch.cat(crops, 0) if len(crops) > 1 else crops[0]
+                fr = range(f0, min(f0 + self.group, self.n_frames))
+                crops, _ = prediction.crop_frames_device([self.frames[f % len(self.frames)] for f in fr],
+                                                         [self.faces[f] for f in fr], 256, 256)
                 lm = self.model.forward_device(crops, "landmarks", n_points=self.n_points)
                 alignment.align_device(crops, lm, self.tmpl, 256, 256, self.scale)
             return lm, None
@@ -469,7 +469,7 @@ def bf16_side_object(lib, args, world, rank, tag):
 def stream_config(lib, args, rank, world, dev):
     """--config 5: the stream as the headline line (no roofline block of its own: its launches have a different batch per
     sequence; the kernels are the ones the other configurations price)."""
-    wl = StreamWorkload(args.stream_dtype, rank, args.n_points)
+    wl = StreamWorkload(args.stream_dtype, rank, args.n_points, group=args.stream_group)
     step = wl.make_step(world, 0)
     dt, _ = timed_region(step, args.steps, args.warmup, world, dev, args.settle_ms / 1e3)
     import torch
@@ -516,6 +516,9 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="extra untimed warm-up before the timed region so a short region starts at settled clocks")
     ap.add_argument("--no-hbm-kernels", action="store_true")
+    ap.add_argument("--stream-group", type=int, default=64,
+                    help="--config 5: frames whose faces share one launch sequence (crop / resize, landmarks, alignment); "
+                         "64 = the whole step (about 500 faces per sequence), 16 = a shorter pipeline (about 130)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend for N > 1: nccl (= RCCL, the measured configuration) or gloo (a dry "
                          "run of the multi-rank flow on a box with fewer GPUs than ranks: ranks share devices, the "

@@ -200,18 +200,50 @@ def face_boxes(faces):
     return out
 
 
-def crop_faces_device(frame, boxes, out_h, out_w):
+def crop_faces_device(frame, boxes, out_h, out_w, out=None, boxes_dev=None):
     """frame: CUDA uint8 [H,W,3]; boxes: list of (x0,y0,x1,y1) -> CUDA uint8 [K,out_h,out_w,3]
-    (crop + bilinear resize, prediction.py:80-82; BGR kept, the FCN loader handles the order)."""
+    (crop + bilinear resize, prediction.py:80-82; BGR kept, the FCN loader handles the order).
+    `out`: write into this contiguous [K,out_h,out_w,3] uint8 tensor (a slice of a larger batch) instead of a new one;
+    `boxes_dev`: the boxes already on the device (int32 [K,4]), e.g. a slice of one upload for several frames."""
     import torch
     lib = _lib.load()
-    k = len(boxes)
-    bt = torch.tensor(np.asarray(boxes, np.int32).reshape(k, 4), dtype=torch.int32, device=frame.device)
-    out = torch.empty((k, out_h, out_w, 3), dtype=torch.uint8, device=frame.device)
-    _lib.check(lib.flm_crop_resize(_lib.stream_ptr(), _lib.ptr(frame.contiguous()), int(frame.shape[0]),
-                                   int(frame.shape[1]), _lib.ptr(bt), k, _lib.ptr(out), out_h, out_w),
-               "flm_crop_resize")
+    k = len(boxes) if boxes_dev is None else int(boxes_dev.shape[0])
+    if boxes_dev is None:
+        boxes_dev = torch.tensor(np.asarray(boxes, np.int32).reshape(k, 4), dtype=torch.int32, device=frame.device)
+    elif boxes_dev.dtype != torch.int32 or not boxes_dev.is_cuda or not boxes_dev.is_contiguous() or boxes_dev.shape[1:] != (4,):
+        raise ValueError("boxes_dev must be a contiguous CUDA int32 [K,4] tensor")
+    if out is None:
+        out = torch.empty((k, out_h, out_w, 3), dtype=torch.uint8, device=frame.device)
+    elif (tuple(out.shape) != (k, out_h, out_w, 3) or out.dtype != torch.uint8 or not out.is_cuda
+          or not out.is_contiguous()):
+        raise ValueError("out must be a contiguous CUDA uint8 [%d,%d,%d,3] tensor" % (k, out_h, out_w))
+    if k:
+        _lib.check(lib.flm_crop_resize(_lib.stream_ptr(), _lib.ptr(frame.contiguous()), int(frame.shape[0]),
+                                       int(frame.shape[1]), _lib.ptr(boxes_dev), k, _lib.ptr(out), out_h, out_w),
+                   "flm_crop_resize")
     return out
+
+
+def crop_frames_device(frames, faces_per_frame, out_h, out_w):
+    """The faces of several frames as ONE batch: frames: CUDA uint8 [H,W,3] tensors, faces_per_frame: per frame a list
+    of detector boxes (x0,y0,x1,y1) -> (CUDA uint8 [K_total,out_h,out_w,3], squared boxes per frame).  One upload of
+    all boxes, one crop / resize launch per frame straight into its slice of the batch (no per-frame allocation, no
+    concatenation): the shape a multi-face stream feeds the landmark model with (prediction.py:99-113 loops per face)."""
+    import torch
+    boxes = [face_boxes(f) for f in faces_per_frame]
+    total = sum(len(b) for b in boxes)
+    dev = frames[0].device if len(frames) else _lib.require_gpu()
+    out = torch.empty((total, out_h, out_w, 3), dtype=torch.uint8, device=dev)
+    if total == 0:
+        return out, boxes
+    flat = np.concatenate([np.asarray(b, np.int32).reshape(len(b), 4) for b in boxes if len(b)], 0)
+    bdev = torch.from_numpy(flat).to(dev)
+    o = 0
+    for frame, b in zip(frames, boxes):
+        if len(b):
+            crop_faces_device(frame, None, out_h, out_w, out=out[o:o + len(b)], boxes_dev=bdev[o:o + len(b)])
+            o += len(b)
+    return out, boxes
 
 
 def detect_marks_batch(img, model, faces, n_points=4, thresh=0.0):

@@ -269,3 +269,22 @@ def test_bf16_faces_do_not_depend_on_their_batch(setup):
     finally:
         model.max_batch = saved
     assert torch.equal(whole, sliced) and torch.equal(whole[:3], three)
+
+
+@pytest.mark.gpu
+def test_crop_frames_device_equals_per_frame_crops(setup):
+    """Several frames' faces as one batch (one box upload, launches into slices of the batch) == the per-frame crops
+    concatenated; a frame without faces contributes nothing."""
+    from flm_amd import prediction
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda", 0)
+    frames = [torch.from_numpy(rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)).to(dev) for _ in range(4)]
+    faces = [[(10, 20, 110, 130), (200, 40, 330, 160)], [], [(5, 5, 60, 70)], [(300, 100, 470, 260), (0, 0, 90, 90), (50, 150, 140, 250)]]
+    crops, boxes = prediction.crop_frames_device(frames, faces, 64, 64)
+    assert crops.shape == (6, 64, 64, 3) and [len(b) for b in boxes] == [2, 0, 1, 3]
+    ref = torch.cat([prediction.crop_faces_device(fr, prediction.face_boxes(fc), 64, 64) for fr, fc in zip(frames, faces) if fc], 0)
+    assert torch.equal(crops, ref)
+    empty, _ = prediction.crop_frames_device(frames[:1], [[]], 64, 64)
+    assert empty.shape == (0, 64, 64, 3)
+    with pytest.raises(ValueError):
+        prediction.crop_faces_device(frames[0], [(0, 0, 10, 10)], 64, 64, out=torch.empty((2, 64, 64, 3), dtype=torch.uint8, device=dev))
