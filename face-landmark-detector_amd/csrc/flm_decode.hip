@@ -389,14 +389,26 @@ __global__ __launch_bounds__(NW * 64) void cand_merge_kernel(CandMergeArgs a) {
   }
 }
 
+// Chunks per face.  The kernel holds 155 registers: three workgroups per CU, 768 on the chip at a time.  What counts is
+// that the launch is whole rounds of those 768 -- 1024 or 1152 workgroups run a second, mostly empty round (batch 512:
+// 4.4-4.7 TB/s instead of 5.6) -- and, among whole rounds, as few chunks per face as possible: every chunk starts with
+// empty lists (~30 serial inserts per class until its threshold has risen) and adds n entries per class to the merge
+// (batch 64: 12 chunks per face = one round, 3.8 TB/s; 24 = two rounds, 3.3; 48: 2.9; tools/bench_hbm.py).
 static void decode_plan(int n, int h, int w, int* chunks, int* chunk_px) {
-  const int HW = h * w;
-  // about 1536 workgroups per launch (6 per CU): fewer and the chip is short of loads in flight (1024: batch 512 at 4.5
-  // TB/s), more and the per-chunk fixed costs -- list set-up, the merge's inputs -- grow (2048: batch 64 at 2.9 TB/s
-  // instead of 3.3, batch 512 at 5.2 instead of 5.6; tools/bench_hbm.py)
-  int s = 1536 / (n > 0 ? n : 1);
-  if (s < 1) s = 1;
-  if (s > 32) s = 32;
+  const int HW = h * w, faces = n > 0 ? n : 1;
+  constexpr int kResident = 768, kMaxChunks = 32;
+  int best_s = 1;
+  double best_u = 0.0;
+  for (int s = 1; s <= kMaxChunks; ++s) {
+    const long long wgs = (long long)faces * s;
+    const long long rounds = (wgs + kResident - 1) / kResident;
+    const double u = (double)wgs / (double)(rounds * kResident);  // how full the rounds are
+    if (u > best_u * 1.05) {  // (ties and near-ties go to the fewer chunks)
+      best_u = u;
+      best_s = s;
+    }
+  }
+  const int s = best_s;
   int px = (HW + s - 1) / s;
   px = (px + PT - 1) / PT * PT;
   *chunk_px = px;
