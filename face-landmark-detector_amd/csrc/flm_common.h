@@ -173,6 +173,7 @@ int igemm_occupancy(size_t lds_bytes);
 void igemm_bf16_big_enable(int on);
 void igemm_bf16_group_n(int gn);
 void igemm_bf16_big_dma(int on);
+void igemm_bf16_big_m16(int on);
 void conv3_halo_enable(int on);
 
 struct ConvTDesc {

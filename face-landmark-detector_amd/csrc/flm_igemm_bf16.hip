@@ -58,8 +58,9 @@ __device__ __forceinline__ void dma_load16(dma_srd srd, unsigned lds_addr, unsig
                : "memory");
 }
 
-template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA>
+template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmArgs a) {
+  static_assert(!M16 || DMA, "the 16x16x32 form exists for the LDS-DMA kernel");
   constexpr int BMt = WM * TM * 32, BNt = WN * TN * 32, NTHR = WM * WN * 64;
   constexpr int RPT = NTHR / 8;                 // rows one staging pass of the workgroup covers
   constexpr int AR = BMt / RPT, BR = BNt / RPT; // staged rows per thread
@@ -102,13 +103,18 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
     __syncthreads();
   }
 
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int wr = wave / WN, wc = wave % WN;
-  const int lr = lane & 31, lh = lane >> 5;
+  // 32x32x16: lane (lr = row of the 32-row tile, lh = which 8 of the slice's 16 k); 16x16x32 (M16): lane (lr = row of the
+  // 16-row tile, lh = which 8 of the slice's 32 k).  Either way the fragment is the 16-byte chunk (slice's first chunk +
+  // lh) ^ swx of row lr, swx = (row >> 1) & 7 as the staging side wrote it.
+  const int lr = M16 ? (lane & 15) : (lane & 31), lh = M16 ? (lane >> 4) : (lane >> 5);
   const int swx = (lr >> 1) & 7;
-  // byte offset of this lane's 16-byte fragment inside a row, per 16-deep slice s: chunk (2s + lh) ^ swx
+  // byte offset of this lane's fragment inside a row, per slice s (M16: two 32-deep slices, chunks 4s + lh; else four
+  // 16-deep ones, chunks 2s + lh)
   int fc[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) fc[s] = ((2 * s + lh) ^ swx) << 4;
+  for (int s = 0; s < 4; ++s) fc[s] = (((M16 ? 4 * (s & 1) : 2 * s) + lh) ^ swx) << 4;
   const int farow = (wr * TM * 32 + lr) * ROWB;
   const int fbrow = A_BYTES + (wc * TN * 32 + lr) * ROWB;
 
@@ -233,14 +239,20 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
 #define FLM_STORE_B(J, STG) \
   *reinterpret_cast<float4*>(smem + (STG) * STAGE + A_BYTES + st_a + (J) * RPT * ROWB) = rb[J];
 
-    f32x16 acc[TM][TN];
+    // 32x32x16: TM x TN tiles of 32 x 32 (16 registers each); M16: 2TM x 2TN tiles of 16 x 16 (4 registers each) -- the same
+    // 128 accumulator registers, the same fragment bytes, twice the MFMAs at half the cycles each.  The 16x16x32 shape
+    // holds a higher clock under this load (tools/mfma_ring_gemm.hip: +2.5..4.5 % on a GEMM of fc7's size, the bf16
+    // outputs equal bit for bit).
+    constexpr int TI = M16 ? 2 * TM : TM, TJ = M16 ? 2 * TN : TN, TR = M16 ? 16 : 32;  // tiles per wave, rows per tile
+    typedef float accv_t __attribute__((ext_vector_type(M16 ? 4 : 16)));
+    accv_t acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 af[TM], bfr[2][TN];
+        for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+    float4 af[TI], bfr[2][TJ];
 
     // One step on stage BUF: 4 slices x SL MFMAs.  W = register set written to the other stage (slice 2),
     // L = register set that receives the loads of the tile after that (slices 0-1).  Branch-free: past the
@@ -327,7 +339,43 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
     }                                                                                                    \
   }
 
-    if (DMA) {
+    // The 16x16x32 form of the step: two 32-deep slices of 2TM x 2TN MFMAs.  Every fragment read of the current stage is
+    // issued by the end of slice 0 (slice 1's fragments are fetched during it), so the barrier sits in the MIDDLE of the
+    // step, and the requests of tile t+2 -- into the stage that barrier has just retired -- spread over the second half.
+#define FLM_DMA_STEP16(BUF)                                                                              \
+  {                                                                                                      \
+    FLM_TILE_PARAMS()                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
+      const int nstage = (s == 0) ? (BUF) : ((BUF) ^ 1);                                                 \
+      _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                   \
+        _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                 \
+          const int slot = (s * TJ + j) * TI + i;                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),          \
+                                                              __builtin_bit_cast(bf16x8, bfr[0][j]), acc[i][j], 0, 0, 0); \
+          /* weight-major order, every fragment single-buffered: weight fragment j is reloaded for the next slice  */ \
+          /* after its eight MFMAs (24 before its next use), im2col fragment i after its last use of the slice      */ \
+          /* (8 before its next) -- 48 fragment registers instead of 64, which spilled                             */ \
+          if (i == TI - 1)                                                                               \
+            bfr[0][j] = *reinterpret_cast<const float4*>(smem + nstage * STAGE + fbrow + j * 16 * ROWB + fc[(s + 1) & 1]); \
+          if (j == TJ - 1)                                                                               \
+            af[i] = *reinterpret_cast<const float4*>(smem + nstage * STAGE + farow + i * 16 * ROWB + fc[(s + 1) & 1]);  \
+          _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                              \
+            if (slot == TI * TJ + (k * TI * TJ) / NLD) {                                                 \
+              if (k < AR) { FLM_DMA_A((k < AR ? k : 0), BUF) }                                           \
+              else { FLM_DMA_B((k >= AR ? k - AR : 0), BUF) }                                            \
+            }                                                                                            \
+          }                                                                                              \
+          if (slot == TI * TJ - 1) {                                                                     \
+            __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): this wave's pieces of the next tile are in LDS */ \
+            __syncthreads();                                                                             \
+          }                                                                                              \
+          __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+    if constexpr (DMA) {
       if (nit > 0) {
         FLM_TILE_PARAMS()
 #pragma unroll
@@ -363,11 +411,17 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
     }
     if (!DMA) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(smem + farow + i * 32 * ROWB + fc[0]);
+    for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float4*>(smem + farow + i * TR * ROWB + fc[0]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const float4*>(smem + fbrow + j * 32 * ROWB + fc[0]);
+    for (int j = 0; j < TJ; ++j) bfr[0][j] = *reinterpret_cast<const float4*>(smem + fbrow + j * TR * ROWB + fc[0]);
 
-    if (DMA) {
+    if constexpr (M16) {
+      for (int it = 0; it < nit; it += 2) {
+        FLM_DMA_STEP16(0)
+        if (it + 1 < nit) FLM_DMA_STEP16(1)
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the requests past the last tile still write LDS
+    } else if constexpr (DMA) {
       for (int it = 0; it < nit; it += 2) {
         FLM_DMA_STEP(0)
         if (it + 1 < nit) FLM_DMA_STEP(1)
@@ -382,6 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
 #undef FLM_DMA_A
 #undef FLM_DMA_B
 #undef FLM_DMA_STEP
+#undef FLM_DMA_STEP16
 
 #undef FLM_TILE_PARAMS
 #undef FLM_LOAD_A
@@ -391,6 +446,89 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
 #undef FLM_BIG_STEP
 #undef FLM_ST_A
 
+    // ---- epilogue of the 16x16x32 form: column = lane & 15, row = 4*(lane >> 4) + r of a 16 x 16 tile -- again four
+    // consecutive rows of one channel per lane, so the same quad transpose gives 8-byte stores; a pooled layer's quad is the
+    // four registers of one tile, and the four values a lane transposes come from four row tiles.
+    if constexpr (M16) {
+      // lane coordinates afresh (lane id from v_mbcnt, wave id from a scalar register): kept alive across the k-loop,
+      // which uses all 256 registers, they -- in the end threadIdx.x itself -- were spilled to scratch
+      const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const int wave = wave_s, wr = wave / WN, wc = wave % WN, lr = lane & 15, lh = lane >> 4;
+      const int q = lane & 3;
+      const bool packed = !a.out_f32 && !(a.cout & 3) && !(a.ldc & 3);
+      const int mrow0 = m0 + wr * TM * 32 + 4 * lh;
+      unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y);
+      float* y32 = reinterpret_cast<float*>(a.y);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + wc * TN * 32 + 16 * j + lr;
+        const bool cok = col < a.cout;
+        const float sc = a.scale[cok ? col : 0], sh = a.shift[cok ? col : 0];
+        const int col4 = col & ~3;
+        if (MMAP == 1) {
+#pragma unroll
+          for (int ib = 0; ib < TI / 4; ++ib) {
+            float v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              v[g] = -3.402823466e38f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float u = fmaf(acc[4 * ib + g][j][e], sc, sh);
+                if (RELU) u = fminf(fmaxf(u, 0.f), a.relu_max);
+                v[g] = fmaxf(v[g], u);
+              }
+            }
+            if (packed) {
+              const uint2 t = quad_transpose_bf16(v[0], v[1], v[2], v[3], q);
+              const int m = mrow0 + 16 * (4 * ib + q);
+              if (cok && m < a.M) *reinterpret_cast<uint2*>(y16 + (size_t)(m >> 2) * a.ldc + col4) = t;
+            } else {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int m = mrow0 + 16 * (4 * ib + g);
+                if (cok && m < a.M) {
+                  const size_t o = (size_t)(m >> 2) * a.ldc + col;
+                  if (!a.out_f32) y16[o] = f2bf(v[g]);
+                  else y32[o] = v[g];
+                }
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            const int m_first = mrow0 + 16 * i;
+            const int nn0 = MMAP == 2 ? m_first % a.n : 0, pos0 = MMAP == 2 ? m_first / a.n : 0;
+            float u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              u[e] = fmaf(acc[i][j][e], sc, sh);
+              if (RELU) u[e] = fminf(fmaxf(u[e], 0.f), a.relu_max);
+            }
+            if (packed) {
+              const uint2 t = quad_transpose_bf16(u[0], u[1], u[2], u[3], q);
+              const int m = m_first + q;
+              if (cok && m < a.M) {
+                const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
+                *reinterpret_cast<uint2*>(y16 + orow * a.ldc + col4) = t;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int m = m_first + e;
+                if (cok && m < a.M) {
+                  const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
+                  if (!a.out_f32) y16[orow * a.ldc + col] = f2bf(u[e]);
+                  else y32[orow * a.ldc + col] = u[e];
+                }
+              }
+            }
+          }
+        }
+      }
+      return;
+    } else {
     // ---- epilogue: y = acc*scale + shift, ReLU, 2x2 max-pool (MMAP 1), store -------------------------------
     // accumulator layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // bf16 outputs (every layer but the last of a chain) leave transposed over lane quads: 8-byte stores of four
@@ -487,6 +625,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
         }
       }
     }
+    }  // (32x32x16 epilogue)
   }
 }
 
@@ -500,12 +639,15 @@ void igemm_bf16_group_n(int gn) { g_group_n = gn; }
 static std::atomic<int> g_big_dma{1};  // operands reach LDS by buffer_load ... lds (256x256 tiles); 0: through staging registers
 void igemm_bf16_big_dma(int on) { g_big_dma = on; }
 
-template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA>
+static std::atomic<int> g_big_m16{1};  // the 256x256 LDS-DMA kernel computes with v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0); same bits
+void igemm_bf16_big_m16(int on) { g_big_m16 = on; }
+
+template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA, bool M16 = false>
 static int launch_big_t(hipStream_t s, IgemmArgs a) {
   constexpr int BMt = WM * TM * 32, BNt = WN * TN * 32;
   constexpr size_t lds = 2 * (size_t)(BMt + BNt) * ROWB + 64;
   static FuncAttrOnce attr;
-  FLM_FUNC_ATTR_ONCE(attr, (&igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA>), lds);
+  FLM_FUNC_ATTR_ONCE(attr, (&igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA, M16>), lds);
   a.mtiles = cdiv(a.M, BMt);
   a.ntiles = cdiv(a.cout, BNt);
   // fc6 (position-major): its 100 MB of weights are the big operand, one weight panel per group keeps it in L2
@@ -514,13 +656,16 @@ static int launch_big_t(hipStream_t s, IgemmArgs a) {
   if (a.gn > a.ntiles) a.gn = a.ntiles;
   a.gm = 32 / a.gn > 0 ? 32 / a.gn : 1;
   const int nblk = cdiv(a.mtiles, a.gm) * a.gm * cdiv(a.ntiles, a.gn) * a.gn;
-  igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA><<<nblk, WM * WN * 64, lds, s>>>(a);
+  igemm_bf16_big_kernel<MMAP, RELU, WM, WN, TM, TN, DMA, M16><<<nblk, WM * WN * 64, lds, s>>>(a);
   FLM_LAUNCH_CHECK("igemm_bf16_big_kernel");
   return 1;
 }
 
 template <int MMAP, bool RELU, int WM, int WN, int TM, int TN>
 static int launch_big(hipStream_t s, const IgemmArgs& a) {
+  // (the position-major instantiation of the 16x16x32 form does not fit 256 registers: fc6 stays on 32x32x16)
+  if (WM == 2 && MMAP != 2 && g_big_dma && g_big_m16)
+    return launch_big_t<MMAP, RELU, WM, WN, TM, TN, (WM == 2), (WM == 2 && MMAP != 2)>(s, a);
   if (WM == 2 && g_big_dma) return launch_big_t<MMAP, RELU, WM, WN, TM, TN, (WM == 2)>(s, a);
   return launch_big_t<MMAP, RELU, WM, WN, TM, TN, false>(s, a);
 }

@@ -190,17 +190,20 @@ def test_bf16_256_row_tiles_equal_128_row_tiles(flm, weights68):
         xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
         outs = {}
         try:
-            # 0: 128x128 tiles; (2, 0): 256-row tiles staged through registers; (2, 1): filled by LDS-DMA
-            for mode, dma in ((0, 0), (2, 0), (2, 1)):
+            # 0: 128x128 tiles; (2, 0): 256-row tiles staged through registers; (2, 1): filled by LDS-DMA, 32x32x16 MFMAs;
+            # (2, 2): LDS-DMA with 16x16x32 MFMAs (the default; the shape sums a k-run of 32 in one instruction)
+            for mode, dma in ((0, 0), (2, 0), (2, 1), (2, 2)):
                 _lib.check(lib.flm_set_tuning(b"bf16_big_tiles", mode), "set_tuning")
-                _lib.check(lib.flm_set_tuning(b"bf16_lds_dma", dma), "set_tuning")
+                _lib.check(lib.flm_set_tuning(b"bf16_lds_dma", 1 if dma else 0), "set_tuning")
+                _lib.check(lib.flm_set_tuning(b"bf16_mfma16", 1 if dma == 2 else 0), "set_tuning")
                 probs = model.forward_device(xd, "probs").cpu().numpy()
                 inter = {k: model.intermediate(k, n, "probs").cpu().numpy() for k in ("f2", "f3", "f4", "f5", "fc6", "fc7")}
                 outs[(mode, dma)] = (probs, inter)
         finally:
             _lib.check(lib.flm_set_tuning(b"bf16_big_tiles", 1), "set_tuning")
             _lib.check(lib.flm_set_tuning(b"bf16_lds_dma", 1), "set_tuning")
-        for key in ((2, 0), (2, 1)):
+            _lib.check(lib.flm_set_tuning(b"bf16_mfma16", 1), "set_tuning")
+        for key in ((2, 0), (2, 1), (2, 2)):
             for k in outs[(0, 0)][1]:
                 assert np.array_equal(outs[(0, 0)][1][k], outs[key][1][k]), (k, key, n, h, w)
             assert np.array_equal(outs[(0, 0)][0], outs[key][0]), key
