@@ -457,6 +457,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
       const int q = lane & 3;
       const bool packed = !a.out_f32 && !(a.cout & 3) && !(a.ldc & 3);
       const int mrow0 = m0 + wr * TM * 32 + 4 * lh;
+      // (an opaque copy of the face count: the reciprocal the row set-up divides by would otherwise stay alive across
+      // the k-loop for the divisions below -- in a vector register, i.e. in scratch)
+      int faces_n = a.n;
+      asm volatile("" : "+s"(faces_n));
       unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y);
       float* y32 = reinterpret_cast<float*>(a.y);
 #pragma unroll
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
 #pragma unroll
           for (int i = 0; i < TI; ++i) {
             const int m_first = mrow0 + 16 * i;
-            const int nn0 = MMAP == 2 ? m_first % a.n : 0, pos0 = MMAP == 2 ? m_first / a.n : 0;
+            const int nn0 = MMAP == 2 ? m_first % faces_n : 0, pos0 = MMAP == 2 ? m_first / faces_n : 0;
             float u[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
               const uint2 t = quad_transpose_bf16(u[0], u[1], u[2], u[3], q);
               const int m = m_first + q;
               if (cok && m < a.M) {
-                const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
+                const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, faces_n, a.h * a.w) : (size_t)m;
                 *reinterpret_cast<uint2*>(y16 + orow * a.ldc + col4) = t;
               }
             } else {
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmAr
               for (int e = 0; e < 4; ++e) {
                 const int m = m_first + e;
                 if (cok && m < a.M) {
-                  const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
+                  const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, faces_n, a.h * a.w) : (size_t)m;
                   if (!a.out_f32) y16[orow * a.ldc + col] = f2bf(u[e]);
                   else y32[orow * a.ldc + col] = u[e];
                 }
@@ -663,9 +667,8 @@ static int launch_big_t(hipStream_t s, IgemmArgs a) {
 
 template <int MMAP, bool RELU, int WM, int WN, int TM, int TN>
 static int launch_big(hipStream_t s, const IgemmArgs& a) {
-  // (the position-major instantiation of the 16x16x32 form does not fit 256 registers: fc6 stays on 32x32x16)
-  if (WM == 2 && MMAP != 2 && g_big_dma && g_big_m16)
-    return launch_big_t<MMAP, RELU, WM, WN, TM, TN, (WM == 2), (WM == 2 && MMAP != 2)>(s, a);
+  if (WM == 2 && g_big_dma && g_big_m16)
+    return launch_big_t<MMAP, RELU, WM, WN, TM, TN, (WM == 2), (WM == 2)>(s, a);
   if (WM == 2 && g_big_dma) return launch_big_t<MMAP, RELU, WM, WN, TM, TN, (WM == 2)>(s, a);
   return launch_big_t<MMAP, RELU, WM, WN, TM, TN, false>(s, a);
 }

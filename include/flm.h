@@ -225,8 +225,8 @@ int flm_profile_filter(const char* layer);
  *                           256-row bf16 implicit-GEMM tiles (csrc/flm_igemm_bf16.hip)
  *   "bf16_lds_dma"          1 (default): the 256x256 tiles fetch their operands with buffer_load ... lds (no staging
  *                           registers, no LDS write pass); 0: global -> registers -> LDS
- *   "bf16_mfma16"           1 (default): the LDS-DMA form of those tiles computes with v_mfma_f32_16x16x32_bf16 (enc3-5,
- *                           fc7; fc6's position-major instantiation keeps 32x32x16); 0: 32x32x16 everywhere.  Same bits
+ *   "bf16_mfma16"           1 (default): the LDS-DMA form of those tiles computes with v_mfma_f32_16x16x32_bf16;
+ *                           0: with 32x32x16.  Same bits
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
  *   "up3_cand8"             bit 0 / bit 1: the bf16 / fp32 candidate launch of the last transposed conv runs the
