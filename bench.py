@@ -255,7 +255,8 @@ class StreamWorkload:
         self.model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
         self.model.load_weights(synth_fcn8_weights(68, seed=2))
         rng = np.random.default_rng(5 + rank)
-        self.frames = [torch.from_numpy(rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)).to(self.dev) for _ in range(8)]
+        # a ring of 8 frames in one allocation: the faces of a whole group are cut in one launch
+        self.frames = torch.from_numpy(rng.integers(0, 256, (8, 1080, 1920, 3), dtype=np.uint8)).to(self.dev)
         self.faces = []
         for _ in range(n_frames):
             fb = []
@@ -276,8 +277,8 @@ class StreamWorkload:
             lm = None
             for f0 in range(0, self.n_frames, self.group):
                 fr = range(f0, min(f0 + self.group, self.n_frames))
-                crops, _ = prediction.crop_frames_device([self.frames[f % len(self.frames)] for f in fr],
-                                                         [self.faces[f] for f in fr], 256, 256)
+                crops, _ = prediction.crop_frames_device(self.frames, [self.faces[f] for f in fr], 256, 256,
+                                                         frame_index=[f % self.frames.shape[0] for f in fr])
                 lm = self.model.forward_device(crops, "landmarks", n_points=self.n_points)
                 alignment.align_device(crops, lm, self.tmpl, 256, 256, self.scale)
             return lm, None

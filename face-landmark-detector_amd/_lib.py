@@ -28,7 +28,7 @@ EXPORTS = [
     "flm_set_tuning", "flm_debug_query", "flm_profile_enable", "flm_profile_filter", "flm_profile_reset", "flm_profile_read", "flm_profile_disable",
     "flm_preprocess",
     "flm_decode_workspace_bytes", "flm_decode",
-    "flm_similarity_from_landmarks", "flm_similarity_from_landmarks_scaled", "flm_warp_affine", "flm_crop_resize",
+    "flm_similarity_from_landmarks", "flm_similarity_from_landmarks_scaled", "flm_warp_affine", "flm_crop_resize", "flm_crop_resize_frames",
 ]
 
 
@@ -146,6 +146,8 @@ def _declare(lib):
     lib.flm_warp_affine.argtypes = [vp, vp, i, i, i, i, vp, vp, i, i]
     lib.flm_crop_resize.restype = i
     lib.flm_crop_resize.argtypes = [vp, vp, i, i, vp, i, vp, i, i]
+    lib.flm_crop_resize_frames.restype = i
+    lib.flm_crop_resize_frames.argtypes = [vp, vp, C.c_size_t, i, i, i, vp, vp, i, vp, i, i]
 
 
 def load():

@@ -761,4 +761,14 @@ int flm_crop_resize(flm_stream_t stream, const uint8_t* frame, int fh, int fw, c
   return launch_crop_resize(static_cast<hipStream_t>(stream), frame, fh, fw, boxes, k, out, oh, ow);
 }
 
+int flm_crop_resize_frames(flm_stream_t stream, const uint8_t* frames, size_t frame_stride, int nframes, int fh, int fw,
+                           const int32_t* boxes, const int32_t* frame_idx, int k, uint8_t* out, int oh, int ow) {
+  if (!frames || !boxes || !frame_idx || !out) {
+    set_error("flm_crop_resize_frames: null argument");
+    return FLM_ERR_ARG;
+  }
+  return launch_crop_resize(static_cast<hipStream_t>(stream), frames, fh, fw, boxes, k, out, oh, ow, frame_idx,
+                            frame_stride, nframes);
+}
+
 }  // extern "C"

@@ -229,7 +229,8 @@ int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n
 int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, int ws, const float* m, float* dst,
                 int hd, int wd);
 int launch_crop_resize(hipStream_t s, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,
-                       uint8_t* out, int oh, int ow);
+                       uint8_t* out, int oh, int ow, const int32_t* frame_idx = nullptr, size_t frame_stride = 0,
+                       int nframes = 0);
 
 // Bijective XCD-aware remap of a 1-D grid: blocks that the dispatcher deals to the same XCD
 // (b % 8) receive consecutive logical ids, so neighbours in logical order share an L2.

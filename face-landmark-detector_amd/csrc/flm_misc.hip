@@ -350,10 +350,22 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int n_src, int&
   w1 = (int)rintf(f * 2048.f);
 }
 
+// frame_idx (may be null): box k is cut from frame frame_idx[k] of `nframes` frames laid out `frame_stride` bytes apart
+// (a ring of stream frames in one allocation): the faces of a whole group of frames in one launch.
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frame, int fh, int fw,
                                                           const int32_t* __restrict__ boxes, uint8_t* __restrict__ out,
-                                                          int oh, int ow) {
+                                                          int oh, int ow, const int32_t* __restrict__ frame_idx,
+                                                          size_t frame_stride, int nframes) {
   const int k = blockIdx.y;
+  if (frame_idx) {
+    const int fi = frame_idx[k];
+    if ((unsigned)fi >= (unsigned)nframes) {  // an index outside the ring: zeros, like a box outside its frame
+      uint8_t* dz = out + (size_t)k * oh * ow * 3;
+      for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < oh * ow * 3; p += gridDim.x * blockDim.x) dz[p] = 0;
+      return;
+    }
+    frame += (size_t)fi * frame_stride;
+  }
   const int cx0 = min(max(boxes[4 * k + 0], 0), fw), cy0 = min(max(boxes[4 * k + 1], 0), fh);
   const int cx1 = min(max(boxes[4 * k + 2], 0), fw), cy1 = min(max(boxes[4 * k + 3], 0), fh);
   const int cw = cx1 - cx0, ch = cy1 - cy0;
@@ -392,14 +404,15 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
 }
 
 int launch_crop_resize(hipStream_t s, const uint8_t* frame, int fh, int fw, const int32_t* boxes, int k,
-                       uint8_t* out, int oh, int ow) {
-  if (k <= 0 || fh <= 0 || fw <= 0 || oh <= 0 || ow <= 0 || k > 65535) {
+                       uint8_t* out, int oh, int ow, const int32_t* frame_idx, size_t frame_stride, int nframes) {
+  if (k <= 0 || fh <= 0 || fw <= 0 || oh <= 0 || ow <= 0 || k > 65535 ||
+      (frame_idx && (nframes <= 0 || frame_stride < (size_t)fh * fw * 3))) {
     set_error("crop_resize: bad sizes");
     return FLM_ERR_SHAPE;
   }
   int bx = cdiv(oh * ow, 256);
   if (bx > 1024) bx = 1024;
-  crop_resize_kernel<<<dim3(bx, k), 256, 0, s>>>(frame, fh, fw, boxes, out, oh, ow);
+  crop_resize_kernel<<<dim3(bx, k), 256, 0, s>>>(frame, fh, fw, boxes, out, oh, ow, frame_idx, frame_stride, nframes);
   FLM_LAUNCH_CHECK("crop_resize_kernel");
   return FLM_OK;
 }

@@ -224,19 +224,37 @@ def crop_faces_device(frame, boxes, out_h, out_w, out=None, boxes_dev=None):
     return out
 
 
-def crop_frames_device(frames, faces_per_frame, out_h, out_w):
-    """The faces of several frames as ONE batch: frames: CUDA uint8 [H,W,3] tensors, faces_per_frame: per frame a list
-    of detector boxes (x0,y0,x1,y1) -> (CUDA uint8 [K_total,out_h,out_w,3], squared boxes per frame).  One upload of
-    all boxes, one crop / resize launch per frame straight into its slice of the batch (no per-frame allocation, no
-    concatenation): the shape a multi-face stream feeds the landmark model with (prediction.py:99-113 loops per face)."""
+def crop_frames_device(frames, faces_per_frame, out_h, out_w, frame_index=None):
+    """The faces of several frames as ONE batch: faces_per_frame: per frame a list of detector boxes (x0,y0,x1,y1) ->
+    (CUDA uint8 [K_total,out_h,out_w,3], squared boxes per frame).  One upload of all boxes; no per-frame allocation,
+    no concatenation: the shape a multi-face stream feeds the landmark model with (prediction.py:99-113 loops per face).
+    frames: either a list of CUDA uint8 [H,W,3] tensors (one crop / resize launch per frame straight into its slice of
+    the batch) or ONE CUDA uint8 [F,H,W,3] tensor -- a ring of stream frames in one allocation -- with `frame_index`
+    naming the ring slot of every entry of faces_per_frame (default 0, 1, ...): then all faces are cut in one launch."""
     import torch
     boxes = [face_boxes(f) for f in faces_per_frame]
     total = sum(len(b) for b in boxes)
-    dev = frames[0].device if len(frames) else _lib.require_gpu()
+    ring = isinstance(frames, torch.Tensor)
+    if ring and (frames.dim() != 4 or frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous()
+                 or frames.shape[3] != 3):
+        raise ValueError("frames must be a list of CUDA uint8 [H,W,3] tensors or one contiguous CUDA uint8 [F,H,W,3] tensor")
+    dev = frames.device if ring else (frames[0].device if len(frames) else _lib.require_gpu())
     out = torch.empty((total, out_h, out_w, 3), dtype=torch.uint8, device=dev)
     if total == 0:
         return out, boxes
     flat = np.concatenate([np.asarray(b, np.int32).reshape(len(b), 4) for b in boxes if len(b)], 0)
+    if ring:
+        slots = list(range(len(boxes))) if frame_index is None else [int(v) for v in frame_index]
+        if len(slots) != len(boxes) or any(not (0 <= v < frames.shape[0]) for v in slots):
+            raise ValueError("frame_index must name a ring slot in [0, %d) for every frame" % frames.shape[0])
+        idx = np.concatenate([np.full(len(b), v, np.int32) for b, v in zip(boxes, slots) if len(b)])
+        both = torch.from_numpy(np.concatenate([flat.reshape(-1), idx])).to(dev)   # one upload: boxes, then slots
+        lib = _lib.load()
+        fh, fw = int(frames.shape[1]), int(frames.shape[2])
+        _lib.check(lib.flm_crop_resize_frames(_lib.stream_ptr(), _lib.ptr(frames), fh * fw * 3, int(frames.shape[0]), fh, fw,
+                                              _lib.ptr(both), _lib.ptr(both[4 * total:]), total, _lib.ptr(out), out_h, out_w),
+                   "flm_crop_resize_frames")
+        return out, boxes
     bdev = torch.from_numpy(flat).to(dev)
     o = 0
     for frame, b in zip(frames, boxes):

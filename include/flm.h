@@ -285,6 +285,13 @@ int flm_warp_affine(flm_stream_t stream, const void* src_dev /*[N,Hs,Ws,3]*/, in
  * every operation), bit-exact against oracle/warp_ref.py; parity with the cv2 binary itself is unpinned. */
 int flm_crop_resize(flm_stream_t stream, const uint8_t* frame_dev, int fh, int fw,
                     const int32_t* boxes_dev /*[K,4]*/, int k, uint8_t* out_dev, int out_h, int out_w);
+/* The same for the faces of SEVERAL frames in one launch (the multi-face stream of prediction.py:99-113, one launch
+ * sequence per group of frames): `frames_dev` holds `nframes` uint8 BGR frames of fh x fw, `frame_stride` bytes apart
+ * (a ring of stream frames in one allocation); box k is cut from frame frame_idx_dev[k] (an index outside [0, nframes)
+ * gives zeros). */
+int flm_crop_resize_frames(flm_stream_t stream, const uint8_t* frames_dev, size_t frame_stride, int nframes, int fh, int fw,
+                           const int32_t* boxes_dev /*[K,4]*/, const int32_t* frame_idx_dev /*[K]*/, int k,
+                           uint8_t* out_dev, int out_h, int out_w);
 
 #ifdef __cplusplus
 }

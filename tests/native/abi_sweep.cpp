@@ -108,6 +108,7 @@ int main() {
   CHECK(flm_similarity_from_landmarks_scaled(nullptr, nullptr, nullptr, 1, 68, 1.0, 1.0, nullptr) == FLM_ERR_ARG);
   CHECK(flm_warp_affine(nullptr, nullptr, 1, 1, 8, 8, nullptr, nullptr, 8, 8) == FLM_ERR_ARG);
   CHECK(flm_crop_resize(nullptr, nullptr, 8, 8, nullptr, 1, nullptr, 8, 8) == FLM_ERR_ARG);
+  CHECK(flm_crop_resize_frames(nullptr, nullptr, 192, 1, 8, 8, nullptr, nullptr, 1, nullptr, 8, 8) == FLM_ERR_ARG);
   CHECK(flm_fcn8_run_layer(nullptr, nullptr, "fc6", nullptr, nullptr, 1, 8, 8, 68, 0) == FLM_ERR_ARG);
   // tuning keys: known accepted, unknown / out of range refused; the layout options are no longer process state
   CHECK(flm_set_tuning("none", 0) == 0 && flm_set_tuning(nullptr, 0) == FLM_ERR_ARG && flm_set_tuning("nope", 1) == FLM_ERR_ARG);

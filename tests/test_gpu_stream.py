@@ -284,6 +284,12 @@ def test_crop_frames_device_equals_per_frame_crops(setup):
     assert crops.shape == (6, 64, 64, 3) and [len(b) for b in boxes] == [2, 0, 1, 3]
     ref = torch.cat([prediction.crop_faces_device(fr, prediction.face_boxes(fc), 64, 64) for fr, fc in zip(frames, faces) if fc], 0)
     assert torch.equal(crops, ref)
+    # the same frames as one ring tensor: one launch, slots named explicitly (and out of order)
+    ring = torch.stack([frames[3], frames[0], frames[2], frames[1]], 0)
+    crops_r, _ = prediction.crop_frames_device(ring, faces, 64, 64, frame_index=[1, 3, 2, 0])
+    assert torch.equal(crops_r, ref)
+    with pytest.raises(ValueError):
+        prediction.crop_frames_device(ring, faces, 64, 64, frame_index=[0, 1, 2, 4])
     empty, _ = prediction.crop_frames_device(frames[:1], [[]], 64, 64)
     assert empty.shape == (0, 64, 64, 3)
     with pytest.raises(ValueError):
