@@ -137,6 +137,13 @@ def test_candidate_path_on_a_non_square_input(flm, weights68, dtype):
     ref = _landmarks(model, xd, 4, 0.0, candidates=False)
     got = _landmarks(model, xd, 4, 0.0, candidates=True)
     assert np.array_equal(got, ref), (dtype, "130 faces")
+    # 200 faces: from 192 the thresholds come from the coalesced kernel (lists of 4 or 8 in registers, flm_decode.hip
+    # cand_tau_small_kernel); n = 3 and 4 take its 4-entry lists, 7 and 8 the 8-entry ones, 9 the wave-per-class kernel
+    xd = torch.from_numpy(rng.integers(0, 256, (200, 96, 160, 3), dtype=np.uint8)).cuda()
+    for n_points in (3, 4, 7, 8, 9):
+        ref = _landmarks(model, xd, n_points, 0.0, candidates=False)
+        got = _landmarks(model, xd, n_points, 0.0, candidates=True)
+        assert np.array_equal(got, ref), (dtype, "200 faces", n_points)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
