@@ -254,6 +254,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::convt_cand8_rows(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "bf16_score1x1")) {  // register-resident 1x1 classifier kernel for 256-channel inputs: 0 off, 1 on
+    flm::score1x1_enable(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_conv3_halo")) {  // halo-resident 3x3 kernel for 64-channel inputs: 0 off, 1 auto, 2 always
     flm::conv3_halo_enable(value);
     return FLM_OK;

@@ -601,6 +601,9 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   // only whole N tiles that hold stored columns are launched
   a.ntiles = cdiv(d.cout, BN);
   if (d.bf16) {
+    const int sk = launch_score1x1_bf16(s, a, d.relu, d.pool, d.posmajor, d.coutpad);
+    if (sk < 0) return sk;
+    if (sk == 1) return FLM_OK;
     const int halo = launch_conv3_halo_bf16(s, a, d.relu, d.pool, d.posmajor);
     if (halo < 0) return halo;
     if (halo == 1) return FLM_OK;

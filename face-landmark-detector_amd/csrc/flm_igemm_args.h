@@ -97,6 +97,8 @@ __device__ __forceinline__ uint2 quad_transpose_bf16(float r0, float r1, float r
 // bf16 layers whose tile grid fills the chip with 256-row tiles (flm_igemm_bf16.hip); returns 1 when it launched,
 // 0 when the shape is left to the 128x128 kernel, < 0 on error.
 int launch_igemm_bf16_big(hipStream_t s, const IgemmArgs& a, int relu, int pool, int posmajor, int coutpad);
+// bf16 1x1 classifiers with 256 input channels and at most 80 columns, fp32 out (flm_score1x1.hip); same return convention.
+int launch_score1x1_bf16(hipStream_t s, const IgemmArgs& a, int relu, int pool, int posmajor, int coutpad);
 // bf16 3x3 'same' layers with 64 input channels (flm_conv3_halo.hip); same return convention.
 int launch_conv3_halo_bf16(hipStream_t s, const IgemmArgs& a, int relu, int pool, int posmajor);
 

@@ -229,6 +229,8 @@ int flm_profile_filter(const char* layer);
  *                           0: with 32x32x16.  Same bits
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
+ *   "bf16_score1x1"         1 (default): 1x1 classifiers on 256-channel bf16 maps (score4, score3) run the kernel that
+ *                           keeps the weights in registers (csrc/flm_score1x1.hip); 0: the implicit GEMM.  Same bits
  *   "up3_cand8"             bit 0 / bit 1: the bf16 / fp32 candidate launch of the last transposed conv runs the
  *                           8-wave kernel (csrc/flm_convt.hip, up3_cand8_kernel); default 1 (bf16); 0: the generic kernel.
  *                           Same keys either way

@@ -209,6 +209,32 @@ def test_bf16_256_row_tiles_equal_128_row_tiles(flm, weights68):
             assert np.array_equal(outs[(0, 0)][0], outs[key][0]), key
 
 
+def test_bf16_score_kernel_equals_implicit_gemm(flm, weights68):
+    """flm_score1x1.hip (1x1 classifiers on 256-channel bf16 maps, weights in registers, 32-deep MFMAs) against the
+    implicit GEMM (16-deep MFMAs, same k order): fuse4, seg_feats and the probabilities bit for bit; M is ragged
+    (3 faces of 96x160: 3 * 12 * 20 = 720 pixels on f3, 45 slices of 16; 180 pixels on f4, the last slice 4 rows)."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    rng = np.random.default_rng(35)
+    for (n, h, w) in ((3, 96, 160), (2, 256, 256), (1, 32, 32)):
+        model = LANDMARKS_MODELS["fcn_8"](68, input_height=h, input_width=w, dtype="bf16")
+        model.load_weights(weights68)
+        xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        outs = {}
+        try:
+            for knob in (0, 1):
+                _lib.check(lib.flm_set_tuning(b"bf16_score1x1", knob), "set_tuning")
+                probs = model.forward_device(xd, "probs").cpu().numpy()
+                inter = {k: model.intermediate(k, n, "probs").cpu().numpy() for k in ("fuse4", "seg_feats")}
+                outs[knob] = (probs, inter)
+        finally:
+            _lib.check(lib.flm_set_tuning(b"bf16_score1x1", 1), "set_tuning")
+        for k in outs[0][1]:
+            assert np.array_equal(outs[0][1][k], outs[1][1][k]), (k, n, h, w)
+        assert np.array_equal(outs[0][0], outs[1][0]), (n, h, w)
+
+
 def test_bf16_halo_conv_equals_implicit_gemm(flm, weights68):
     """flm_conv3_halo.hip (3x3, 64 input channels, halo + weights resident in LDS) consumes k in the implicit GEMM's
     order: bit-identical outputs.  Vanilla enc2 exercises the pooled epilogue, VGG's block1_conv2 / block2_conv1 the
