@@ -229,6 +229,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::igemm_bf16_big_m16(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "bf16_halo_mfma16")) {  // the halo-resident 3x3 kernel on v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0)
+    flm::conv3_halo_m16(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_lds_dma")) {  // 256x256 tiles: operands by buffer_load ... lds (1) or through registers (0)
     flm::igemm_bf16_big_dma(value);
     return FLM_OK;

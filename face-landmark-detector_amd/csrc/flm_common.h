@@ -175,6 +175,7 @@ void igemm_bf16_group_n(int gn);
 void igemm_bf16_big_dma(int on);
 void igemm_bf16_big_m16(int on);
 void conv3_halo_enable(int on);
+void conv3_halo_m16(int on);
 void score1x1_enable(int on);
 
 struct ConvTDesc {

@@ -227,6 +227,8 @@ int flm_profile_filter(const char* layer);
  *                           registers, no LDS write pass); 0: global -> registers -> LDS
  *   "bf16_mfma16"           1 (default): the LDS-DMA form of those tiles computes with v_mfma_f32_16x16x32_bf16;
  *                           0: with 32x32x16.  Same bits
+ *   "bf16_halo_mfma16"      1 (default): the halo-resident 3x3 kernel (enc2) computes with v_mfma_f32_16x16x32_bf16 too;
+ *                           0: with 32x32x16.  Same bits
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
  *   "bf16_score1x1"         1 (default): 1x1 classifiers on 256-channel bf16 maps (score4, score3) run the kernel that

@@ -56,7 +56,7 @@ def test_tuning_knobs_and_workspace_layout():
     import ctypes as C
     from flm_amd import _lib
     lib = _lib.load()
-    for key, val in ((b"none", 0), (b"bf16_big_tiles", 1), (b"bf16_group_n", 0), (b"bf16_lds_dma", 1), (b"bf16_mfma16", 1), (b"bf16_score1x1", 1), (b"bf16_conv3_halo", 1)):
+    for key, val in ((b"none", 0), (b"bf16_big_tiles", 1), (b"bf16_group_n", 0), (b"bf16_lds_dma", 1), (b"bf16_mfma16", 1), (b"bf16_halo_mfma16", 1), (b"bf16_score1x1", 1), (b"bf16_conv3_halo", 1)):
         assert lib.flm_set_tuning(key, val) == 0, key
     assert lib.flm_set_tuning(b"no_such_knob", 1) != 0 and b"no_such_knob" in lib.flm_last_error()
     assert lib.flm_set_tuning(b"bf16_group_n", 3) != 0

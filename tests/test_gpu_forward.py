@@ -252,18 +252,23 @@ def test_bf16_halo_conv_equals_implicit_gemm(flm, weights68):
         xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
         outs = {}
         try:
-            for mode in (0, 2):
+            # (0, .): implicit GEMM; (2, 0): halo kernel on 32x32x16 MFMAs; (2, 1): on 16x16x32 (the default shape)
+            for mode, m16 in ((0, 0), (2, 0), (2, 1)):
                 _lib.check(lib.flm_set_tuning(b"bf16_conv3_halo", mode), "set_tuning")
-                outs[mode] = model.forward_device(xd, "probs").cpu().numpy()
+                _lib.check(lib.flm_set_tuning(b"bf16_halo_mfma16", m16), "set_tuning")
+                key = (mode, m16)
+                outs[key] = model.forward_device(xd, "probs").cpu().numpy()
                 if name == "fcn_8":
-                    outs[mode] = (outs[mode], model.intermediate("f2", n, "probs").cpu().numpy())
+                    outs[key] = (outs[key], model.intermediate("f2", n, "probs").cpu().numpy())
         finally:
             _lib.check(lib.flm_set_tuning(b"bf16_conv3_halo", 1), "set_tuning")
-        if name == "fcn_8":
-            assert np.array_equal(outs[0][1], outs[2][1]), (name, n, h, w, "f2")
-            assert np.array_equal(outs[0][0], outs[2][0]), (name, n, h, w)
-        else:
-            assert np.array_equal(outs[0], outs[2]), (name, n, h, w)
+            _lib.check(lib.flm_set_tuning(b"bf16_halo_mfma16", 1), "set_tuning")
+        for key in ((2, 0), (2, 1)):
+            if name == "fcn_8":
+                assert np.array_equal(outs[(0, 0)][1], outs[key][1]), (name, n, h, w, "f2", key)
+                assert np.array_equal(outs[(0, 0)][0], outs[key][0]), (name, n, h, w, key)
+            else:
+                assert np.array_equal(outs[(0, 0)], outs[key]), (name, n, h, w, key)
 
 
 def test_fcn32_forward(flm, weights68):

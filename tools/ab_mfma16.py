@@ -17,7 +17,7 @@ model.load_weights(synth_fcn8_weights(68, 2))
 x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 256, 256, 3), dtype=np.uint8)).cuda()
 for rnd in range(3):
     for knob in (0, 1):
-        _lib.check(lib.flm_set_tuning(b"bf16_mfma16", knob), "set_tuning")
+        _lib.check(lib.flm_set_tuning(os.environ.get("KNOB", "bf16_mfma16").encode(), knob), "set_tuning")
         for _ in range(3):
             model.forward_device(x, "landmarks", n_points=4)
         torch.cuda.synchronize()
@@ -30,5 +30,5 @@ for rnd in range(3):
         layers = bench.read_profile(lib)
         lib.flm_profile_disable()
         print("mfma16=%d: sum %.3f ms " % (knob, sum(layers.values())) +
-              " ".join("%s %.3f" % (k, layers[k]) for k in ("enc3", "enc4", "enc5", "fc6", "fc7")), flush=True)
-_lib.check(lib.flm_set_tuning(b"bf16_mfma16", 1), "set_tuning")
+              " ".join("%s %.3f" % (k, layers[k]) for k in ("enc2", "enc3", "enc4", "enc5", "fc6", "fc7")), flush=True)
+_lib.check(lib.flm_set_tuning(os.environ.get("KNOB", "bf16_mfma16").encode(), 1), "set_tuning")
