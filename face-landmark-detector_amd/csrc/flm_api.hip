@@ -225,6 +225,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::igemm_bf16_big_enable(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "f32_two_level")) {  // fp32 implicit GEMMs: two-level accumulation (1) or one chain per output (0)
+    flm::igemm_f32_group(value ? 0 : -1);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_mfma16")) {  // 256x256 LDS-DMA tiles on v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0)
     flm::igemm_bf16_big_m16(value);
     return FLM_OK;

@@ -170,6 +170,7 @@ struct IgemmDesc {
 };
 int launch_igemm(hipStream_t s, const IgemmDesc& d);
 int igemm_occupancy(size_t lds_bytes);
+void igemm_f32_group(int steps);
 void igemm_bf16_big_enable(int on);
 void igemm_bf16_group_n(int gn);
 void igemm_bf16_big_dma(int on);

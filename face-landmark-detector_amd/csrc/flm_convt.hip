@@ -727,9 +727,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // assembly: through the builtin hipcc would order every later ds_read behind the pending request (vmcnt(0)).
 typedef int dma_srd __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma_piece(dma_srd srd, unsigned lds_addr, unsigned voffset, int soffset) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+  // M0 (the LDS base of the request) is an operand the compiler sets itself ("{m0}"), so it knows the register is
+  // written; the s_nop is the wait state the ISA asks for between a scalar write of M0 and a buffer_load ... lds
+  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :
-               : "s"(lds_addr), "v"(voffset), "s"(srd), "s"(soffset)
+               : "v"(voffset), "s"(srd), "s"(soffset), "{m0}"(lds_addr)
                : "memory");
 }
 }  // namespace cand8

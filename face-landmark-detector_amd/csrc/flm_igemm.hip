@@ -65,8 +65,9 @@ __device__ __forceinline__ void mfma_slot(const float4& a0, const float4& a1, co
   }
 }
 
-template <bool BF, int MMAP, bool RELU>
+template <bool BF, int MMAP, bool RELU, bool TWO = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
+  static_assert(!TWO || !BF, "the multi-level accumulation is the fp32 (parity) form");
   constexpr int ES = BF ? 2 : 4;    // operand element size
   constexpr int EPC = 16 / ES;      // elements per 16-byte chunk
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   if (pass) __syncthreads();  // the previous tile's last fragment reads are done before LDS is refilled
 
   // ---- staging role: rows r0+32j, 16-byte chunk c8 of the 128-byte k-run ----------------------
-  const int c8 = tid & 7, r0 = tid >> 3;
+  // (TWO: the loads write LDS themselves, lane l of a wave at byte 16*l of the wave's 1 KiB piece = 8 rows, so the XOR
+  // swizzle moves to the source side: the lane at physical chunk tid&7 fetches the logical chunk that lives there)
+  const int c8 = TWO ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7), r0 = tid >> 3;
   int pn[4], py[4], px[4];
   bool pv[4];
 #pragma unroll
@@ -207,6 +210,210 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     wrow[j] = reinterpret_cast<const char*>(a.wt) + ((size_t)(n0 + r0 + 32 * j) * a.K + EPC * c8) * ES;
   const char* xbase = reinterpret_cast<const char*>(a.x);
 
+  // fragment read offsets (floats): rows 64*wr + 32*i + lr of A, 64*wc + 32*j + lr of B; the XOR term of
+  // the swizzle depends on lr only, the chunk is 2*t + lh
+  int fa0, fa1, fb0, fb1, fc0, fc1, fc2, fc3;
+  {
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int swx = (lr >> 1) & 7;
+    fa0 = (64 * wr + lr) * BK, fa1 = fa0 + 32 * BK;
+    fb0 = (64 * wc + lr) * BK, fb1 = fb0 + 32 * BK;
+    fc0 = ((0 + lh) ^ swx) << 2, fc1 = ((2 + lh) ^ swx) << 2, fc2 = ((4 + lh) ^ swx) << 2, fc3 = ((6 + lh) ^ swx) << 2;
+  }
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+
+  // ---- fp32 parity form: LDS-DMA operand ring + three-level accumulation -------------------------------------------
+  // A v_mfma_f32_32x32x2_f32 stream is bit for bit ONE fmaf chain per output: K = 576 .. 12,544 sequential roundings,
+  // 4-7e-7 relative RMS per layer against the float64 oracle where a blocked CPU summation leaves 2-5e-7 -- enough to
+  // push 3 of 4,352 top-4 landmarks past the 1e-4 px bar.  Here every k-step (32 products: one
+  // filter tap of one 32-channel chunk) sums in the MFMA accumulators from ZERO; the step sums are added, in the
+  // order of the dense (chunk, tap) sequence, into a second accumulator set, and that set is added into a third and
+  // cleared whenever the dense step index enters a new GROUP of grp ~ sqrt(K/32) steps: chains of
+  // 32 + grp + K/(32 grp) roundings instead of K (fc6: 32 + 19 + 21 instead of 12,544).  Groups are cut on the DENSE
+  // index and a step whose tap the tile skips contributes exact zeros either way, so an output's summation tree does
+  // not depend on which padding taps its tile skips, i.e. on the batch the face sits in.
+  // The 128 registers of the two extra sets are the staging registers of the other form and its slack: operands reach
+  // LDS by buffer_load_dwordx4 ... lds (flm_igemm_args.h), zero padding by the buffer bounds check.  Tile t+2 is
+  // requested in group 3 of step t, into the stage that step's barrier has just retired, and waited for (vmcnt(0)) at
+  // the barrier of step t+1: three quarters of a step (3,072 MFMA cycles) of cover.
+  // The third level is 128 VALU instructions behind a wave-uniform branch right after the barrier of a group's first
+  // step (no LDS read is in flight there: at the end of the step the branch cost an lgkmcnt(0) per step, 3 % of the
+  // layer).  The second level costs no matrix time: the first slot of a step adds each tile's accumulators to the second
+  // set (16 VALU adds in the shadow of the neighbouring tile's MFMA; that tile's last MFMA was issued four MFMAs
+  // earlier) and restarts the tile with C = 0.
+  if constexpr (TWO) {
+    f32x16 sum00, sum01, sum10, sum11;   // second level: step sums of the current group
+    f32x16 top00, top01, top10, top11;   // third level: group sums
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum00[r] = sum01[r] = sum10[r] = sum11[r] = top00[r] = top01[r] = top10[r] = top11[r] = 0.f;
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    typedef __attribute__((address_space(3))) char lds_char;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned dma_a = (unsigned)(size_t)((lds_char*)smem_raw) + wave_s * 8 * 128;  // this wave's 8 rows of A stage 0
+    const unsigned dma_b = dma_a + 2 * TILE_F * 4;
+    const int xbias = (a.pad * a.w + a.pad) * a.cin * 4;  // largest negative tap displacement, in bytes
+    const dma_srd xdma = dma_make_srd(reinterpret_cast<const char*>(a.x) - xbias);
+    const dma_srd wdma = dma_make_srd(reinterpret_cast<const char*>(a.wt) + (size_t)n0 * a.K * 4);
+    const unsigned wrow0 = ((unsigned)r0 * (unsigned)a.K + 4u * c8) * 4u;
+    const int wstep = 32 * a.K * 4;  // bytes between the weight rows of consecutive j
+    // (py << 16) | px of the filter centre; rows past M get py = 0x7000: out of bounds for every tap, they never load
+    int pyx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pyx[j] = ((pv[j] ? py[j] : 0x7000) << 16) | px[j];
+    const int off_a = (fa0 + fc0) * 4, off_b = (fb0 + fc0) * 4;  // byte offsets of k-group 0 in an A / B stage
+
+    unsigned long long rem = rem0;
+    int cur_chunk = chunk0 < a.cpt ? chunk0 : 0;
+    int cur_tap = __builtin_ctzll(rem);
+    int ld_ky = 0, ld_kx = 0, ld_delta = 0, ld_koff = 0, ld_gid = 0;
+    // group (of grp consecutive dense steps) of the step before the current one, the current one and the next
+    int g_prev = 0, g_cur = 0, g_nx1 = 0;
+
+#define FLM_TILE_PARAMS()                                                    \
+  {                                                                          \
+    const int ty = (cur_tap * a.kw_magic) >> 16;                             \
+    ld_ky = ty - a.pad;                                                      \
+    ld_kx = cur_tap - ty * a.kw - a.pad;                                     \
+    ld_delta = (ld_ky * a.w + ld_kx) * a.cin * 4 + xbias + cur_chunk * 128;  \
+    ld_koff = cur_tap * a.cin * 4 + cur_chunk * 128;                         \
+    ld_gid = ((cur_chunk * ntaps + cur_tap) * a.grp_magic) >> 16;            \
+    rem &= rem - 1;                                                          \
+    if (rem == 0) {                                                          \
+      rem = tapmask;                                                         \
+      if (++cur_chunk == a.cpt) cur_chunk = 0; /* (past the slice's end: requests nobody reads) */ \
+    }                                                                        \
+    cur_tap = __builtin_ctzll(rem);                                          \
+  }
+#define FLM_DMA_A(J, STG)                                                                                    \
+  {                                                                                                          \
+    const int iy = (pyx[J] >> 16) + ld_ky, ix = (pyx[J] & 0xffff) + ld_kx;                                   \
+    const bool ok_ = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;                          \
+    dma_load16(xdma, dma_a + (STG) * (TILE_F * 4) + (J) * 32 * 128, ok_ ? rowoff[J] : kOobOffset, ld_delta); \
+  }
+#define FLM_DMA_B(J, STG) dma_load16(wdma, dma_b + (STG) * (TILE_F * 4) + (J) * 32 * 128, wrow0, (J) * wstep + ld_koff);
+  // Fragment addresses: chunk (2t + lh) ^ swx = ((lh ^ swx) ^ 2t), so the address of k-group t is the address of group
+  // 0 with bits 5-6 flipped by t: two address registers and one v_xor per read instead of eight registers (the XOR is
+  // applied to an opaque copy, or hipcc hoists the eight sums out of the loop again).
+#define FLM_READ_FRAGS(AF0, AF1, BF0, BF1, T, STG)                                                          \
+  {                                                                                                         \
+    int oa_ = off_a, ob_ = off_b;                                                                           \
+    asm volatile("" : "+v"(oa_), "+v"(ob_));                                                                \
+    const char* pa_ = smem_raw + ((oa_ ^ ((T) << 5)) + (STG) * (TILE_F * 4));                               \
+    const char* pb_ = smem_raw + ((ob_ ^ ((T) << 5)) + (STG) * (TILE_F * 4) + 2 * TILE_F * 4);              \
+    AF0 = *reinterpret_cast<const float4*>(pa_);                                                            \
+    AF1 = *reinterpret_cast<const float4*>(pa_ + 32 * BK * 4);                                              \
+    BF0 = *reinterpret_cast<const float4*>(pb_);                                                            \
+    BF1 = *reinterpret_cast<const float4*>(pb_ + 32 * BK * 4);                                              \
+  }
+#define FLM_SLOT_x 0
+#define FLM_SLOT_y 1
+#define FLM_SLOT_z 2
+#define FLM_SLOT_w 3
+#define FLM_MFMA4(AF0, AF1, BF0, BF1, E)                                                     \
+  mfma_slot<false, FLM_SLOT_##E>(AF0, AF1, BF0, BF1, acc00, acc01, acc10, acc11);            \
+  __builtin_amdgcn_sched_barrier(0);
+  // first slot of a step: close the previous step tile by tile and restart the tile from C = 0
+#define FLM_FLUSH1(SUM, ACC, AV, BV)                                                         \
+  SUM += ACC;                                                                                \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, zero16, 0, 0, 0);                       \
+  __builtin_amdgcn_sched_barrier(0);
+#define FLM_MFMA4_FLUSH(AF0, AF1, BF0, BF1)                                                  \
+  FLM_FLUSH1(sum00, acc00, AF0.x, BF0.x)                                                     \
+  FLM_FLUSH1(sum01, acc01, AF0.x, BF1.x)                                                     \
+  FLM_FLUSH1(sum10, acc10, AF1.x, BF0.x)                                                     \
+  FLM_FLUSH1(sum11, acc11, AF1.x, BF1.x)
+
+  // One step on stage BUF (compile-time).
+#define FLM_STEP2(BUF)                                                                                \
+  {                                                                                                   \
+    FLM_TILE_PARAMS()                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    /* group 0 (fragments fetched during the previous step's group 3) */                              \
+    FLM_MFMA4_FLUSH(afx0, afx1, bfx0, bfx1)                                                           \
+    FLM_READ_FRAGS(afy0, afy1, bfy0, bfy1, 1, BUF)                                                    \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y)                                                              \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z)                                                              \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w)                                                              \
+    /* group 1 */                                                                                     \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, x) FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, 2, BUF)               \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, y)                                                              \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, z)                                                              \
+    FLM_MFMA4(afy0, afy1, bfy0, bfy1, w)                                                              \
+    /* group 2; then the step's only barrier: every wave has fetched the fragments of group 3 by now, so this */ \
+    /* stage is dead, and this wave's pieces of the next one have landed (vmcnt(0)) */                \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, x) FLM_READ_FRAGS(afy0, afy1, bfy0, bfy1, 3, BUF)               \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, y)                                                              \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, z)                                                              \
+    FLM_MFMA4(afx0, afx1, bfx0, bfx1, w)                                                              \
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                                               \
+    __syncthreads();                                                                                  \
+    /* third level, right behind the barrier: the second set holds the steps before this one; if this step opened */ \
+    /* a new group they are a closed group */                                                         \
+    if (g_prev != g_cur) {                                                                            \
+      top00 += sum00; top01 += sum01; top10 += sum10; top11 += sum11;                                 \
+      sum00 = zero16; sum01 = zero16; sum10 = zero16; sum11 = zero16;                                 \
+    }                                                                                                 \
+    /* group 3: the next step's first fragments come from the next stage; tile it+2 is requested into this one */ \
+    {                                                                                                 \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, x)                                                            \
+      FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, 0, (BUF) ^ 1)                                            \
+      FLM_DMA_A(0, BUF) FLM_DMA_B(0, BUF)                                                             \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_DMA_A(1, BUF) FLM_DMA_B(1, BUF)                        \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_DMA_A(2, BUF) FLM_DMA_B(2, BUF)                        \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_DMA_A(3, BUF) FLM_DMA_B(3, BUF)                        \
+    }                                                                                                 \
+    g_prev = g_cur;                                                                                   \
+    g_cur = g_nx1;                                                                                    \
+    g_nx1 = ld_gid;                                                                                   \
+  }
+
+    // prologue: tile 0 -> stage 0, tile 1 -> stage 1 (past the end: a tile nobody reads)
+    if (nit > 0) {
+      FLM_TILE_PARAMS()
+      g_prev = g_cur = ld_gid;
+      FLM_DMA_A(0, 0) FLM_DMA_A(1, 0) FLM_DMA_A(2, 0) FLM_DMA_A(3, 0)
+      FLM_DMA_B(0, 0) FLM_DMA_B(1, 0) FLM_DMA_B(2, 0) FLM_DMA_B(3, 0)
+      FLM_TILE_PARAMS()
+      g_nx1 = ld_gid;
+      FLM_DMA_A(0, 1) FLM_DMA_A(1, 1) FLM_DMA_A(2, 1) FLM_DMA_A(3, 1)
+      FLM_DMA_B(0, 1) FLM_DMA_B(1, 1) FLM_DMA_B(2, 1) FLM_DMA_B(3, 1)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    float4 afx0, afx1, bfx0, bfx1, afy0, afy1, bfy0, bfy1;
+    afy0 = afy1 = bfy0 = bfy1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, 0, 0)
+    for (int it = 0; it < nit; it += 2) {
+      FLM_STEP2(0)
+      if (it + 1 < nit) FLM_STEP2(1)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the requests past the last tile still write LDS
+    acc00 = top00 + (sum00 + acc00);
+    acc01 = top01 + (sum01 + acc01);
+    acc10 = top10 + (sum10 + acc10);
+    acc11 = top11 + (sum11 + acc11);
+#undef FLM_TILE_PARAMS
+#undef FLM_DMA_A
+#undef FLM_DMA_B
+#undef FLM_READ_FRAGS
+#undef FLM_MFMA4
+#undef FLM_FLUSH1
+#undef FLM_MFMA4_FLUSH
+#undef FLM_SLOT_x
+#undef FLM_SLOT_y
+#undef FLM_SLOT_z
+#undef FLM_SLOT_w
+#undef FLM_STEP2
+  }
+
+  if constexpr (!TWO) {
   // ---- software pipeline ---------------------------------------------------------------------------
   // Step t computes tile t from LDS[t&1]; in the SAME step, spread between the 64 MFMAs, it issues the
   // global loads of tile t+2 into one register set and writes tile t+1 (loaded during step t-1, so long
@@ -261,19 +468,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   *reinterpret_cast<float4*>(As + sbuf * TILE_F + swz(r0 + 32 * J, c8)) = OK ? RA : make_float4(0.f, 0.f, 0.f, 0.f);
 #define FLM_STORE_B(J, RB) *reinterpret_cast<float4*>(Bs + sbuf * TILE_F + swz(r0 + 32 * J, c8)) = RB;
 
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lr = lane & 31, lh = lane >> 5;
-  // fragment read offsets (floats): rows 64*wr + 32*i + lr of A, 64*wc + 32*j + lr of B; the XOR term of
-  // the swizzle depends on lr only, the chunk is 2*t + lh
-  const int swx = (lr >> 1) & 7;
-  const int fa0 = (64 * wr + lr) * BK, fa1 = fa0 + 32 * BK;
-  const int fb0 = (64 * wc + lr) * BK, fb1 = fb0 + 32 * BK;
-  const int fc0 = ((0 + lh) ^ swx) << 2, fc1 = ((2 + lh) ^ swx) << 2, fc2 = ((4 + lh) ^ swx) << 2,
-            fc3 = ((6 + lh) ^ swx) << 2;
-
-  f32x16 acc00, acc01, acc10, acc11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
 
 #define FLM_READ_FRAGS(AF0, AF1, BF0, BF1, FC)                                   \
   AF0 = *reinterpret_cast<const float4*>(Ab + fa0 + FC);                         \
@@ -380,10 +574,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #undef FLM_SLOT_w
 #undef FLM_STEP
 
+  }  // (!TWO)
+
   // ---- epilogue: y = acc*scale + shift, ReLU, 2x2 max-pool (MMAP 1), store ---------------------
   // accumulator layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   f32x16 acc[2][2];
   acc[0][0] = acc00; acc[0][1] = acc01; acc[1][0] = acc10; acc[1][1] = acc11;
+  // (TWO: lane coordinates afresh -- lane id from v_mbcnt, wave id from a scalar register -- so that nothing derived from
+  // threadIdx.x stays alive across the k-loop, which uses nearly all of the 256 registers)
+  const int lane_e = TWO ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : lane;
+  const int wave_e = TWO ? __builtin_amdgcn_readfirstlane(wave) : wave;
+  const int wr = wave_e >> 1, wc = wave_e & 1, lr = lane_e & 31, lh = lane_e >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 64 * wc + 32 * j + lr;
@@ -447,13 +648,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   }  // pass
 }
 
-template <bool BF, int MMAP, bool RELU>
+template <bool BF, int MMAP, bool RELU, bool TWO = false>
 static int launch_t(hipStream_t s, const IgemmArgs& a) {
   const size_t lds = sizeof(float) * 4 * TILE_F + 64;
   static FuncAttrOnce attr;
-  FLM_FUNC_ATTR_ONCE(attr, (&igemm_kernel<BF, MMAP, RELU>), lds);
+  FLM_FUNC_ATTR_ONCE(attr, (&igemm_kernel<BF, MMAP, RELU, TWO>), lds);
   const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
-  igemm_kernel<BF, MMAP, RELU><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
+  igemm_kernel<BF, MMAP, RELU, TWO><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
   FLM_LAUNCH_CHECK("igemm_kernel");
   return FLM_OK;
 }
@@ -506,12 +707,18 @@ int igemm_occupancy(size_t lds_bytes) {
   return nb;
 }
 
-template <bool BF>
+template <bool BF, bool TWO = false>
 static int dispatch(hipStream_t s, const IgemmDesc& d, const IgemmArgs& a) {
-  if (d.pool) return d.relu ? launch_t<BF, 1, true>(s, a) : launch_t<BF, 1, false>(s, a);
-  if (d.posmajor) return d.relu ? launch_t<BF, 2, true>(s, a) : launch_t<BF, 2, false>(s, a);
-  return d.relu ? launch_t<BF, 0, true>(s, a) : launch_t<BF, 0, false>(s, a);
+  if (d.pool) return d.relu ? launch_t<BF, 1, true, TWO>(s, a) : launch_t<BF, 1, false, TWO>(s, a);
+  if (d.posmajor) return d.relu ? launch_t<BF, 2, true, TWO>(s, a) : launch_t<BF, 2, false, TWO>(s, a);
+  return d.relu ? launch_t<BF, 0, true, TWO>(s, a) : launch_t<BF, 0, false, TWO>(s, a);
 }
+
+// fp32 summation: 0 = multi-level (igemm_kernel<.., TWO>, the default), -1 = the single-chain kernel with register
+// staging (A/B of accuracy and speed, tools/).  Unlike the other knobs this one changes the fp32 summation order, i.e.
+// result bits (never their validity).
+static std::atomic<int> g_f32_group{0};
+void igemm_f32_group(int steps) { g_f32_group = steps; }
 
 int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   const int es = d.bf16 ? 2 : 4;
@@ -561,6 +768,7 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   // (32 workgroups at batch 64), fc6 / fc7 at batches of a few faces (32 workgroups walk 205 MB of weights)
   a.ksplit = 1;
   a.gm = a.gn = 1;
+  a.grp_magic = 0;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
   // The slice count is a step function of the tile count, the same for fc6 and fc7 (<= 64 tiles, i.e. up to 4
@@ -572,11 +780,15 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   // 16 workgroups x 36 k-steps for one face otherwise)
   const int faces = d.n > 0 ? d.n : 1;
   const bool few_faces = d.kh * d.kw > 1 && d.cout < 1024 && faces <= 4 && tiles <= 64 * faces;
-  const int tile_cap = (d.cout >= 1024 || few_faces) ? 256 : 64;  // the wide fc layers keep splitting until they fill the chip
+  // a 1x1 classifier on the fc grid (score5: K = 4096 into one N tile) splits at EVERY batch, always 8 ways beyond 16
+  // faces: with a tile cap its sums changed at 129 faces, the only layer whose bits depended on the batch beyond the
+  // documented brackets (tools/debug_batch_invariance.py)
+  const bool narrow_1x1 = d.kh * d.kw == 1 && d.cin / bke >= 32 && d.cout <= BN;
+  const int tile_cap = narrow_1x1 ? 0x7fffffff : ((d.cout >= 1024 || few_faces) ? 256 : 64);  // the wide fc layers keep splitting until they fill the chip
   if (d.splitk_ws && !d.res && stride == 1 && tiles <= tile_cap && (!d.pool || (a.M & 3) == 0) &&
       (d.kh * d.kw == 1 ? a.cpt >= 32 : (a.cpt >= 4 && (d.cout >= 1024 || tiles <= 16 * faces || few_faces))) &&
       (d.relu != 2 || d.pool)) {
-    int ks = tiles <= 64 ? 8 : (tiles <= 128 ? 4 : 2);
+    int ks = (tiles <= 64 || narrow_1x1) ? 8 : (tiles <= 128 ? 4 : 2);
     if (few_faces && tiles > 16 * faces) ks = 8;  // (capped to 9 * cpt / 8 below: the same count for 1..4 faces)
     int per = d.kh * d.kw == 1 ? 8 : 1;  // chunks a slice should at least hold
     if (d.kh * d.kw == 1 && tiles <= 8) {  // score5 up to 16 faces: 1..8 workgroups walking K = 4096 otherwise
@@ -611,7 +823,52 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
     if (big < 0) return big;
     if (big == 1) return FLM_OK;
   }
-  int rc = d.bf16 ? dispatch<true>(s, d, a) : dispatch<false>(s, d, a);
+  int rc;
+  const int f32_knob = g_f32_group.load(std::memory_order_relaxed);
+  if (d.bf16) {
+    rc = dispatch<true>(s, d, a);
+  } else if (f32_knob < 0) {
+    rc = dispatch<false>(s, d, a);
+  } else {
+    // groups of the third accumulation level: floor(sqrt(k-steps per output)) steps, at least 2
+    const int dense = d.kh * d.kw * a.cpt;
+    if (dense >= 8192) {
+      set_error("igemm: %d k-steps per output exceed the group divider's range", dense);
+      return FLM_ERR_SHAPE;
+    }
+    int grp = 2;
+    while ((grp + 1) * (grp + 1) <= dense) ++grp;
+    a.grp_magic = (65536 + grp - 1) / grp;
+    // buffer offsets at or above 0x80000000 mean "zero padding", so the operand a launch addresses stays below 2 GiB:
+    // larger batches go in slices of whole faces (faces are independent rows of the GEMM)
+    const long long face_in = (long long)d.h * d.w * d.cin * 4,
+                    face_out = (long long)(d.pool ? (ho / 2) * (wo / 2) : ho * wo) * d.ldc * 4;
+    const long long lim = (1ll << 31) - (1ll << 22);
+    if (face_in >= lim) {
+      set_error("igemm: one face exceeds the 2 GiB buffer range of the fp32 kernel");
+      return FLM_ERR_SHAPE;
+    }
+    const int max_faces = (int)(lim / face_in);
+    if (d.n <= max_faces) {
+      rc = dispatch<false, true>(s, d, a);
+    } else {
+      if (a.ksplit > 1) {  // (split-K is for a handful of faces: never reached)
+        set_error("igemm: batch slicing is not built for split-K layers");
+        return FLM_ERR_UNSUPPORTED;
+      }
+      rc = FLM_OK;
+      for (int f0 = 0; f0 < d.n && rc == FLM_OK; f0 += max_faces) {
+        IgemmArgs b = a;
+        b.n = d.n - f0 < max_faces ? d.n - f0 : max_faces;
+        b.x = reinterpret_cast<const char*>(a.x) + (size_t)f0 * face_in;
+        b.y = reinterpret_cast<char*>(a.y) + (size_t)f0 * face_out;
+        if (a.res) b.res = reinterpret_cast<const char*>(a.res) + (size_t)f0 * face_out;
+        b.M = b.n * ho * wo;
+        b.mtiles = cdiv(b.M, BM);
+        rc = dispatch<false, true>(s, d, b);
+      }
+    }
+  }
   if (rc || a.ksplit <= 1) return rc;
   const size_t total = (size_t)a.M * d.ldc;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -25,6 +25,7 @@ struct IgemmArgs {
   int kw_magic; // ceil(65536 / kw): tap / kw == (tap * kw_magic) >> 16 for tap < 64
   int ksplit;   // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to `part`
   float* part;  // [ksplit][M][ldc]
+  int grp_magic;  // fp32 three-level accumulation: ceil(65536 / steps per group); group = (dense step * grp_magic) >> 16
   int gm, gn;   // flm_igemm_bf16.hip: tiles are dealt in groups of gm x gn (the 32 workgroups resident on one XCD)
 };
 
@@ -92,6 +93,33 @@ __device__ __forceinline__ uint2 quad_transpose_bf16(float r0, float r1, float r
   const bool low = q < 2;
   const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(low ? t23 : t01), 0x4E, 0xf, 0xf, true);  // [2,3,0,1]
   return make_uint2(low ? t01 : recv, low ? recv : t23);
+}
+
+// Operands are fetched with raw buffer loads (buffer_load_dwordx4 v, voffset, srd, soffset offen):
+//   * the per-row byte offset of the centre pixel is a constant VGPR; the filter tap and channel chunk of the
+//     k-step are wave-uniform and ride in the scalar offset, so a load costs no vector address arithmetic;
+//   * rows of the im2col operand that fall on zero padding (or past M) get the offset 0x80000000, beyond
+//     num_records: the buffer unit returns zeros, so no validity flag travels from the load to the LDS write
+//     and the write needs no select.
+// The resource base is moved back by the largest negative tap displacement so that the scalar offset is
+// never negative.
+constexpr unsigned kOobOffset = 0x80000000u;
+constexpr int kSrdFlags = 0x00020000;  // raw dword buffer, gfx9 DATA_FORMAT field
+
+// LDS-DMA: buffer_load_dwordx4 ... lds writes lane l's 16 bytes to LDS address M0 + 16*l, no VGPR destination.
+// Inline assembly: through the builtin hipcc orders every later ds_read behind the pending request (vmcnt(0)).
+typedef int dma_srd __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_srd dma_make_srd(const void* base) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  return (dma_srd){(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), 0x7fffffff, kSrdFlags};
+}
+__device__ __forceinline__ void dma_load16(dma_srd srd, unsigned lds_addr, unsigned voffset, int soffset) {
+  // M0 (the LDS base of the request) is an operand the compiler sets itself ("{m0}"), so it knows the register is
+  // written; the s_nop is the wait state the ISA asks for between a scalar write of M0 and a buffer_load ... lds
+  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voffset), "s"(srd), "s"(soffset), "{m0}"(lds_addr)
+               : "memory");
 }
 
 // bf16 layers whose tile grid fills the chip with 256-row tiles (flm_igemm_bf16.hip); returns 1 when it launched,

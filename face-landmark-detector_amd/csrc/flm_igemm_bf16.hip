@@ -34,29 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int ROWB = 128;  // bytes of one operand row per k-step
 
-// Operands are fetched with raw buffer loads (buffer_load_dwordx4 v, voffset, srd, soffset offen):
-//   * the per-row byte offset of the centre pixel is a constant VGPR; the filter tap and channel chunk of the
-//     k-step are wave-uniform and ride in the scalar offset, so a load costs no vector address arithmetic;
-//   * rows of the im2col operand that fall on zero padding (or past M) get the offset 0x80000000, beyond
-//     num_records: the buffer unit returns zeros, so no validity flag travels from the load to the LDS write
-//     and the write needs no select.
-// The resource base is moved back by the largest negative tap displacement so that the scalar offset is
-// never negative.
-constexpr unsigned kOobOffset = 0x80000000u;
-constexpr int kSrdFlags = 0x00020000;  // raw dword buffer, gfx9 DATA_FORMAT field
-
-// LDS-DMA: buffer_load_dwordx4 ... lds writes lane l's 16 bytes to LDS address M0 + 16*l, no VGPR destination.
-typedef int dma_srd __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ dma_srd dma_make_srd(const void* base) {
-  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-  return (dma_srd){(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), 0x7fffffff, kSrdFlags};
-}
-__device__ __forceinline__ void dma_load16(dma_srd srd, unsigned lds_addr, unsigned voffset, int soffset) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(lds_addr), "v"(voffset), "s"(srd), "s"(soffset)
-               : "memory");
-}
+// (raw buffer loads, the out-of-bounds offset and the LDS-DMA request: flm_igemm_args.h)
 
 template <int MMAP, bool RELU, int WM, int WN, int TM, int TN, bool DMA, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 1) void igemm_bf16_big_kernel(IgemmArgs a) {

@@ -219,7 +219,8 @@ int flm_profile_enable(int max_records);
 /* Bracket only the launches of one layer ("fc6", ...; NULL or "" = every launch).  Every event pair costs a few
  * microseconds of stream time, so a timed region that only needs the dominant kernel's duration filters on it. */
 int flm_profile_filter(const char* layer);
-/* A/B performance knobs: they never change results or memory layouts; key "none" is always accepted, unknown keys
+/* A/B performance knobs: they never change memory layouts, and -- with the one exception of "f32_two_level", which
+ * selects between two fp32 summation orders -- never results; key "none" is always accepted, unknown keys
  * fail.  Atomic integers read at launch time; meant for A/B runs (tools/tune.py) and for tests that force a code path:
  *   "bf16_big_tiles"        0 off | 1 auto (default) | 2 whenever the shape allows | 3 auto + 256x128 tiles
  *                           256-row bf16 implicit-GEMM tiles (csrc/flm_igemm_bf16.hip)
@@ -229,6 +230,10 @@ int flm_profile_filter(const char* layer);
  *                           0: with 32x32x16.  Same bits
  *   "bf16_halo_mfma16"      1 (default): the halo-resident 3x3 kernel (enc2) computes with v_mfma_f32_16x16x32_bf16 too;
  *                           0: with 32x32x16.  Same bits
+ *   "f32_two_level"         1 (default): the fp32 implicit GEMMs sum every 32-product k-step from zero and add the step
+ *                           sums into a second accumulator set (chains of 32 + K/32 roundings, operands by LDS-DMA;
+ *                           csrc/flm_igemm.hip); 0: one fmaf chain of K per output (round 2's kernel).  Both are valid
+ *                           fp32 evaluations of the layer; the bits differ
  *   "bf16_group_n"          weight panels per tile group of that kernel (0 default, else a power of two <= 32)
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
  *   "bf16_score1x1"         1 (default): 1x1 classifiers on 256-channel bf16 maps (score4, score3) run the kernel that

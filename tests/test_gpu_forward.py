@@ -119,6 +119,59 @@ def test_forward_256_full_resolution(flm, weights68):
         assert np.linalg.norm((lm - e64), axis=-1)[decided].mean() / 256.0 <= 1e-4
 
 
+def test_fp32_two_level_accumulation_beats_the_single_chain(flm, weights68):
+    """The fp32 implicit GEMMs sum every 32-product k-step from zero and add the step sums into a second accumulator
+    set (csrc/flm_igemm.hip, TWO).  Against the float64 oracle every layer must be closer than the single fmaf chain
+    (knob f32_two_level = 0: round 2's kernel) and at least as close as the float32 CPU oracle's blocked sums."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    from oracle import fcn_ref
+    lib = _lib.load()
+    n = 2
+    crops = np.random.default_rng(1).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in crops])
+    _, i64 = fcn_ref.fcn8_logits_ref(x_ref, weights68, torch.float64, return_intermediates=True)
+    _, i32 = fcn_ref.fcn8_logits_ref(x_ref, weights68, torch.float32, return_intermediates=True)
+    rms = lambda a, b: float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(crops).cuda()
+    names = ("f2", "f3", "f4", "f5", "fc6", "fc7")
+    err = {}
+    try:
+        for two in (0, 1):
+            _lib.check(lib.flm_set_tuning(b"f32_two_level", two), "set_tuning")
+            model.forward_device(xd, "probs")
+            torch.cuda.synchronize()
+            err[two] = {k: rms(model.intermediate(k, n, "probs").cpu().numpy()[..., : i64[k].shape[-1]], i64[k]) for k in names}
+    finally:
+        _lib.check(lib.flm_set_tuning(b"f32_two_level", 1), "set_tuning")
+    e32 = {k: rms(i32[k], i64[k]) for k in names}
+    print("relative RMS error vs the float64 oracle:", {k: "%.2g / %.2g / %.2g" % (err[0][k], err[1][k], e32[k]) for k in names},
+          "(single chain / two-level / float32 CPU oracle)")
+    for k in names:
+        assert err[1][k] < 0.6 * err[0][k], (k, err)
+        assert err[1][k] <= 1.05 * e32[k], (k, err[1][k], e32[k])
+
+
+def test_fp32_batches_beyond_2gib_run_in_face_slices(flm, weights68):
+    """The fp32 kernel addresses its operands through a 2 GiB buffer window (offsets from 0x80000000 mean zero padding):
+    at 512 faces f1 is exactly 2 GiB, so enc2 runs as two launches over whole faces.  Faces are independent rows of
+    every GEMM: the landmarks must be the bits of the same faces run 64 at a time."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    n = 512
+    crops = np.random.default_rng(7).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(crops).cuda()
+    lm = model.forward_device(xd, "landmarks", n_points=4).cpu().numpy()
+    model._ws.clear()
+    for lo in (0, 448):     # the first batch of 64 and the one that holds the second slice's only face
+        part = model.forward_device(xd[lo:lo + 64].contiguous(), "landmarks", n_points=4).cpu().numpy()
+        assert np.array_equal(part, lm[lo:lo + 64]), lo
+    assert np.isfinite(lm).all() and (lm >= 0).all()
+
+
 def test_forward_generic_classes(flm):
     from flm_amd.weights import synth_fcn8_weights
     for c in (5, 21):

@@ -25,6 +25,11 @@ def main():
     from oracle import fcn_ref
     from test_gpu_baseline_configs import centroid_ref, topn_of_maps
     n, c = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 68
+    for kv in filter(None, os.environ.get("KNOBS", "").split(",")):   # e.g. KNOBS=f32_two_level=0
+        from flm_amd import _lib
+        k, v = kv.split("=")
+        _lib.check(_lib.load().flm_set_tuning(k.encode(), int(v)), "set_tuning")
+        print("knob", k, "=", v)
     w = synth_fcn8_weights(c, seed=2)
     crops = np.random.default_rng(1).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
     model = LANDMARKS_MODELS["fcn_8"](c, input_height=256, input_width=256)
@@ -50,7 +55,7 @@ def main():
           "(everything before it), rms |hip - o64| %.3g" % (np.sqrt(np.mean((lg_hip[:2] - lg_from_seg) ** 2)),
           np.sqrt(np.mean((lg_from_seg - l64) ** 2)), np.sqrt(np.mean((lg_hip[:2] - l64) ** 2))))
     for npts in (4, 25):
-        ea, eb, ec, sm = [], [], [], []
+        ea, eb, ec, sm, worst = [], [], [], [], []
         for i in range(n):
             l64 = fcn_ref.fcn8_logits_ref(x_ref[i:i + 1], w, torch.float64).reshape(-1, c)
             l32 = fcn_ref.fcn8_logits_ref(x_ref[i:i + 1], w, torch.float32).reshape(-1, c)
@@ -64,6 +69,14 @@ def main():
                 ii, _, _ = topn_of_maps(pm, npts)
                 lst.append(np.abs(centroid_ref(pm, ii) - ref)[dec])
             ii, _, _ = topn_of_maps(pr_hip[i], npts)
+            eb_full = np.abs(centroid_ref(pr_hip[i], ii) - ref).max(-1)
+            ea_full = np.abs(centroid_ref(pa, topn_of_maps(pa, npts)[0]) - ref).max(-1)
+            for cls in np.argsort(-np.where(dec, eb_full, 0))[:2]:
+                sel = idx[:, cls]
+                worst.append((eb_full[cls], i, int(cls), ea_full[cls],
+                              (pr_hip[i][sel, cls] / p64[sel, cls] - 1).tolist(), (pa[sel, cls] / p64[sel, cls] - 1).tolist(),
+                              (lg_hip[i][sel, cls] - l64[sel, cls]).tolist(), p64[sel, cls].tolist(),
+                              [(int(t) // 264, int(t) % 264) for t in sel]))
             sm.append((np.abs(np.take_along_axis(pr_hip[i], ii, 0) - np.take_along_axis(pa, ii, 0)) /
                        np.take_along_axis(pa, ii, 0)).max())
             if npts == 4 and i == 0:
@@ -76,6 +89,10 @@ def main():
             print("top-%d %-46s max %.3g px  p99 %.3g  median %.3g  over 1e-4: %d of %d" %
                   (npts, name, e.max(), np.quantile(e, 0.99), np.median(e), (e > 1e-4).sum(), e.size))
         print("top-%d kernel softmax vs softmax64(HIP logits), relative, at the selected pixels: max %.3g" % (npts, max(sm)))
+        for e, i, cls, eaa, rb, ra, dl, pv, px in sorted(worst, reverse=True)[:6]:
+            print("  worst: face %d class %d err B %.3g (A %.3g); rel err of the selected probs B %s | A %s; logit err %s; p %s; (y,x) %s"
+                  % (i, cls, e, eaa, ["%.2g" % v for v in rb], ["%.2g" % v for v in ra], ["%.2g" % v for v in dl],
+                     ["%.3g" % v for v in pv], px))
 
 
 if __name__ == "__main__":
