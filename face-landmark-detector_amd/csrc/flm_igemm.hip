@@ -31,6 +31,14 @@
 //      heaviest and the i-th lightest back to back, so all workgroups carry about the same load.
 #include "flm_igemm_args.h"
 
+// Developer variants (tools/ab_variants.py builds the file with -DFLM_IGEMM_VAR=<mask>; 0 in every shipped build):
+// 1 no third accumulation level, 2 two fragment address registers + one v_xor per read instead of eight registers
+// (chunk (2t + lh) ^ swx = ((lh ^ swx) ^ 2t): group t's address is group 0's with bits 5-6 flipped; frees six registers,
+// costs 1.5 % of a layer).
+#ifndef FLM_IGEMM_VAR
+#define FLM_IGEMM_VAR 0
+#endif
+
 namespace flm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -79,11 +87,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  // MMAP 2: a workgroup owns the tile pair (i, MT-1-i); otherwise one tile
-  const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
+  // MMAP 2: a workgroup owns the tile pair (i, MT-1-i); otherwise one tile.  (TWO: one tile per workgroup here as well,
+  // handed out heaviest first -- workgroups are dealt to the CUs in index order, so the light tiles fill the tail, as in
+  // flm_igemm_bf16.hip.  The loop over the pair kept set-up values alive across a k-loop that has no register to spare.)
+  constexpr bool PAIR = (MMAP == 2) && !TWO;
+  const int mslots = PAIR ? (a.mtiles + 1) / 2 : a.mtiles;
   const int mslot = L % mslots, nt = L / mslots;
   const int n0 = nt * BN;
-  const int npass = (MMAP == 2 && mslot != a.mtiles - 1 - mslot) ? 2 : 1;
+  const int npass = (PAIR && mslot != a.mtiles - 1 - mslot) ? 2 : 1;
   int pair_mt[2] = {mslot, mslot};
   if (MMAP == 2) {
     // rank the tiles by work, heaviest first (ties by index); LDS scratch = the still unused A buffer
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       ord[rank] = t;
     }
     __syncthreads();
-    pair_mt[0] = ord[mslot];
+    pair_mt[0] = TWO ? __builtin_amdgcn_readfirstlane(ord[mslot]) : ord[mslot];
     pair_mt[1] = ord[a.mtiles - 1 - mslot];
     __syncthreads();
   }
@@ -298,15 +309,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     dma_load16(xdma, dma_a + (STG) * (TILE_F * 4) + (J) * 32 * 128, ok_ ? rowoff[J] : kOobOffset, ld_delta); \
   }
 #define FLM_DMA_B(J, STG) dma_load16(wdma, dma_b + (STG) * (TILE_F * 4) + (J) * 32 * 128, wrow0, (J) * wstep + ld_koff);
-  // Fragment addresses: chunk (2t + lh) ^ swx = ((lh ^ swx) ^ 2t), so the address of k-group t is the address of group
-  // 0 with bits 5-6 flipped by t: two address registers and one v_xor per read instead of eight registers (the XOR is
-  // applied to an opaque copy, or hipcc hoists the eight sums out of the loop again).
 #define FLM_READ_FRAGS(AF0, AF1, BF0, BF1, T, STG)                                                          \
   {                                                                                                         \
     int oa_ = off_a, ob_ = off_b;                                                                           \
-    asm volatile("" : "+v"(oa_), "+v"(ob_));                                                                \
-    const char* pa_ = smem_raw + ((oa_ ^ ((T) << 5)) + (STG) * (TILE_F * 4));                               \
-    const char* pb_ = smem_raw + ((ob_ ^ ((T) << 5)) + (STG) * (TILE_F * 4) + 2 * TILE_F * 4);              \
+    if (FLM_IGEMM_VAR & 2) asm volatile("" : "+v"(oa_), "+v"(ob_)); /* (opaque, or the sums are hoisted) */ \
+    const int fct_ = (T) == 0 ? fc0 : ((T) == 1 ? fc1 : ((T) == 2 ? fc2 : fc3));                            \
+    const char* pa_ = !(FLM_IGEMM_VAR & 2) ? smem_raw + (fa0 + fct_) * 4 + (STG) * (TILE_F * 4)             \
+                                           : smem_raw + ((oa_ ^ ((T) << 5)) + (STG) * (TILE_F * 4));        \
+    const char* pb_ = !(FLM_IGEMM_VAR & 2) ? smem_raw + (fb0 + fct_) * 4 + (STG) * (TILE_F * 4) + 2 * TILE_F * 4 \
+                                           : smem_raw + ((ob_ ^ ((T) << 5)) + (STG) * (TILE_F * 4) + 2 * TILE_F * 4); \
     AF0 = *reinterpret_cast<const float4*>(pa_);                                                            \
     AF1 = *reinterpret_cast<const float4*>(pa_ + 32 * BK * 4);                                              \
     BF0 = *reinterpret_cast<const float4*>(pb_);                                                            \
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     __syncthreads();                                                                                  \
     /* third level, right behind the barrier: the second set holds the steps before this one; if this step opened */ \
     /* a new group they are a closed group */                                                         \
-    if (g_prev != g_cur) {                                                                            \
+    if (!(FLM_IGEMM_VAR & 1) && g_prev != g_cur) {                                                    \
       top00 += sum00; top01 += sum01; top10 += sum10; top11 += sum11;                                 \
       sum00 = zero16; sum01 = zero16; sum10 = zero16; sum11 = zero16;                                 \
     }                                                                                                 \
@@ -653,7 +664,7 @@ static int launch_t(hipStream_t s, const IgemmArgs& a) {
   const size_t lds = sizeof(float) * 4 * TILE_F + 64;
   static FuncAttrOnce attr;
   FLM_FUNC_ATTR_ONCE(attr, (&igemm_kernel<BF, MMAP, RELU, TWO>), lds);
-  const int mslots = (MMAP == 2) ? (a.mtiles + 1) / 2 : a.mtiles;
+  const int mslots = (MMAP == 2 && !TWO) ? (a.mtiles + 1) / 2 : a.mtiles;
   igemm_kernel<BF, MMAP, RELU, TWO><<<dim3(mslots * a.ntiles, a.ksplit > 1 ? a.ksplit : 1), 256, lds, s>>>(a);
   FLM_LAUNCH_CHECK("igemm_kernel");
   return FLM_OK;
