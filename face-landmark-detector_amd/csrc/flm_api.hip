@@ -152,7 +152,10 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
       W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, cand_sub_for(co, n_points)) * 16 * g.MT);  // sampled maxima
       W.tau = take(cur, sizeof(float) * (size_t)n * C);
       // expected keys per class: the n-th of 1/64 of the pixels ranks about 64*n-th overall; x4 head room
+      // (never below one 64-key block: a huge cap_div then still takes the documented overflow fallback instead of
+      // sizing an empty list, which the candidate launch rejects)
       W.cand_cap = (int)align_up((size_t)C * 64 * n_points * 4 / co.cap_div, 64);
+      if (W.cand_cap < 64) W.cand_cap = 64;
       W.cand = take(cur, sizeof(unsigned long long) * (size_t)n * W.cand_cap);
       W.cand_cnt = take(cur, sizeof(unsigned) * ((size_t)n + 1));
     }
@@ -246,7 +249,8 @@ int flm_set_tuning(const char* key, int value) {
               "flm_fcn_workspace_bytes_opts / flm_fcn_forward_opts", key);
     return FLM_ERR_ARG;
   }
-  if (!strcmp(key, "up3_cand8")) {  // candidate launch of up3: bit 0 bf16, bit 1 fp32 take the 8-wave kernel (default 3)
+  if (!strcmp(key, "up3_cand8")) {  // candidate launch of up3: bit 0 = bf16 takes the 8-wave kernel (default 1), bit 2 = its
+                                    // 4-wave shape; bit 1 (the fp32 form) is accepted and ignored since round 3
     if (value < 0 || value > 7) {
       set_error("flm_set_tuning: up3_cand8 must be in [0,7]");
       return FLM_ERR_ARG;
@@ -255,8 +259,8 @@ int flm_set_tuning(const char* key, int value) {
     return FLM_OK;
   }
   if (!strcmp(key, "up3_cand8_rows")) {  // phase rows per workgroup of that kernel: 0 automatic, else 1, 2, 4 or 8
-    if (value < 0 || value > 32 || (value & (value - 1))) {
-      set_error("flm_set_tuning: up3_cand8_rows must be 0 or a power of two <= 32");
+    if (value < 0 || value > 8 || (value & (value - 1))) {
+      set_error("flm_set_tuning: up3_cand8_rows must be 0, 1, 2, 4 or 8");
       return FLM_ERR_ARG;
     }
     flm::convt_cand8_rows(value);

@@ -519,15 +519,38 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
                 ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), xb, ACC[nt][m], 0, 0, 0); \
             }                                                                                       \
           } else {                                                                                  \
+            /* fp32: K = 4 * Cp products per output are NOT one fmaf chain: the SUBG k groups of an LDS chunk (96   */ \
+            /* products) sum in a side accumulator from zero and the sub-chain sums are added in order -- 96 + 3    */ \
+            /* roundings instead of 272 (up3's own rounding was the largest single share of the logits' error,      */ \
+            /* DESIGN 2; sub-chains of 64 cost three registers more than the kernel has)                             */ \
+            /* (the first sub-chain sums in the phase's accumulators themselves, cleared at the phase start)        */ \
+            const bool sub_first = g % SUBG == 0;                                                   \
+            const bool sub_last = (g == G - 1) || ((g + 1) % SUBG == 0);                            \
+            if (g < SUBG) {                                                                         \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                   \
+                _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                   \
+                  ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, ACC[nt][m], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                   \
+                  ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, ACC[nt][m], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                   \
+                  ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, ACC[nt][m], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                   \
+                  ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, ACC[nt][m], 0, 0, 0); \
+              }                                                                                     \
+            } else {                                                                                \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
               _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
-                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, ACC[nt][m], 0, 0, 0); \
+                tmpacc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, xf[nt][g].x, sub_first ? (f32x4){0.f, 0.f, 0.f, 0.f} : tmpacc[nt][m], 0, 0, 0); \
               _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
-                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, ACC[nt][m], 0, 0, 0); \
+                tmpacc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, xf[nt][g].y, tmpacc[nt][m], 0, 0, 0); \
               _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
-                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, ACC[nt][m], 0, 0, 0); \
+                tmpacc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, xf[nt][g].z, tmpacc[nt][m], 0, 0, 0); \
               _Pragma("unroll") for (int m = 0; m < (MTP); ++m)                                     \
-                ACC[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, ACC[nt][m], 0, 0, 0); \
+                tmpacc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, xf[nt][g].w, tmpacc[nt][m], 0, 0, 0); \
+              if (sub_last) {                                                                       \
+                _Pragma("unroll") for (int m = 0; m < (MTP); ++m) ACC[nt][m] += tmpacc[nt][m];      \
+              }                                                                                     \
+            }                                                                                       \
             }                                                                                       \
           }                                                                                         \
         }                                                                                           \
@@ -537,6 +560,8 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       ++seq;                                                                                        \
     }                                                                                               \
   }
+  constexpr int SUBG = GCH_F32;          // fp32: k groups per sub-chain of the two-level sum (= one LDS chunk: 96 products)
+  f32x4 tmpacc[BF ? 1 : NT][MT];         // fp32: the running sub-chain
   constexpr bool SHARE_OK = C68;         // kernels that may meet the shared tile-4 layout
   f32x4 x4g[2][BF ? 1 : NT];             // fp32: tile-4 sums of the current and the previous group of four phases (bf16: LDS)
 #pragma unroll
@@ -1154,8 +1179,9 @@ int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub) {
   return 4 * cdiv((hi + 1) * (wi + 1), 64 * nt) * sub;
 }
 
-// A/B knob (flm_set_tuning "up3_cand8"): bit 0 the 8-wave kernel above for the bf16 candidate launch, bit 1 for the fp32
-// one (default 1: in fp32 the two kernels take the same time, and the generic one stays on the headline path), 0 the generic kernel; same keys either way, so it never changes results or layouts
+// A/B knob (flm_set_tuning "up3_cand8"): bit 0 the 8-wave kernel above for the bf16 candidate launch (default 1), bit 2
+// its 4-wave shape, 0 the generic kernel; same keys either way, so it never changes results or layouts.  Bit 1 asked for
+// an fp32 form (a tie at best); retired when the generic kernel's fp32 sum became two-level
 static std::atomic<int> g_cand8{1};
 void convt_cand8_enable(int on) { g_cand8.store(on, std::memory_order_relaxed); }
 
@@ -1198,9 +1224,11 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
       return FLM_ERR_UNSUPPORTED;
     }
     const int c8 = g_cand8.load(std::memory_order_relaxed);  // bit 0: bf16, bit 1: fp32, bit 2: the 4-wave shape
-    if ((d.s & 3) == 0 && d.s >= 4 && (long long)d.s * d.s * cand8::Cfg<false>::PHASE_BYTES < 0x7fffffffll) {
+    // (the 8-wave kernel decodes a phase as (b >> log2 s, b & (s - 1)): s a power of two, checked above)
+    if ((d.s & 3) == 0 && d.s >= 4 && (d.s & (d.s - 1)) == 0 && (long long)d.s * d.s * cand8::Cfg<false>::PHASE_BYTES < 0x7fffffffll) {
       if (d.g.bf16 && (c8 & 1)) return (c8 & 4) ? launch_cand8<true, 4, 3>(st, a) : launch_cand8<true, 8, 9>(st, a);
-      if (!d.g.bf16 && (c8 & 2)) return (c8 & 4) ? launch_cand8<false, 4, 3>(st, a) : launch_cand8<false, 8, 9>(st, a);
+      // (bit 1, the fp32 form of that kernel, is retired: the generic kernel's fp32 sum is two-level since round 3 and
+      // the 8-wave kernel, a tie in fp32 at best, was not given the same summation tree -- its keys would differ)
     }
     return d.g.bf16 ? launch_t<5, 9, true, 2, 1, true>(st, a) : launch_t<5, 17, false, 1, 1, true>(st, a);
   }

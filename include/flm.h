@@ -238,9 +238,10 @@ int flm_profile_filter(const char* layer);
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
  *   "bf16_score1x1"         1 (default): 1x1 classifiers on 256-channel bf16 maps (score4, score3) run the kernel that
  *                           keeps the weights in registers (csrc/flm_score1x1.hip); 0: the implicit GEMM.  Same bits
- *   "up3_cand8"             bit 0 / bit 1: the bf16 / fp32 candidate launch of the last transposed conv runs the
- *                           8-wave kernel (csrc/flm_convt.hip, up3_cand8_kernel); default 1 (bf16); 0: the generic kernel.
- *                           Same keys either way
+ *   "up3_cand8"             bit 0: the bf16 candidate launch of the last transposed conv runs the 8-wave kernel
+ *                           (csrc/flm_convt.hip, up3_cand8_kernel); bit 2: its 4-wave x 2-workgroup shape; default 1;
+ *                           0: the generic kernel.  Same keys either way.  Bit 1 (an fp32 form of that kernel) is
+ *                           accepted and ignored: the fp32 path always runs the generic kernel
  *   "up3_cand8_rows"        phase rows one workgroup of that kernel walks with the same input fragments: 0 (default)
  *                           chosen from the batch, else 1, 2, 4 or 8
  * The options that change the workspace layout ("landmark_candidates", "candidate_*") are per-call arguments:

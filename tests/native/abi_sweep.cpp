@@ -23,7 +23,7 @@ int main() {
   const int hw[][2] = {{32, 32}, {64, 96}, {96, 160}, {256, 256}, {416, 608}};
   const int cs[] = {1, 5, 21, 68, 96};
   const int npts[] = {0, 1, 4, 9, 25, 32, 33, 64};
-  flm_forward_opts o_def, o_off, o_small, o_sub;
+  flm_forward_opts o_def, o_off, o_small, o_sub, o_tiny;
   flm_forward_opts_init(&o_def);
   flm_forward_opts_init(&o_off);
   o_off.landmark_candidates = 0;
@@ -31,8 +31,10 @@ int main() {
   o_small.candidate_cap_div = 4096;
   flm_forward_opts_init(&o_sub);
   o_sub.candidate_sub_phases = 16;
+  flm_forward_opts_init(&o_tiny);
+  o_tiny.candidate_cap_div = 0x7fffffff;  // lists of one 64-key block: always the overflow fallback, never an empty list
   CHECK(o_def.struct_size == sizeof(flm_forward_opts) && o_def.landmark_candidates == 1 && o_def.candidate_cap_div == 1);
-  const flm_forward_opts* opts[] = {nullptr, &o_def, &o_off, &o_small, &o_sub};
+  const flm_forward_opts* opts[] = {nullptr, &o_def, &o_off, &o_small, &o_sub, &o_tiny};
   const char* names[] = {"f1", "f2", "f3", "f4", "f5", "fc6", "fc7", "score5", "fuse4", "seg_feats", "probs",
                          "cand_sub", "cand_tau", "cand_keys", "cand_cnt", "cand_cap", "nonsense", ""};
   for (int arch = 0; arch < 8; ++arch)
@@ -57,6 +59,7 @@ int main() {
                       for (const char* nm : names) {
                         const int64_t off = flm_fcn8_workspace_offset_opts(nm, n, d[0], d[1], c, dt, om, dm, np, o);
                         CHECK(off >= -1 && (off < 0 || (size_t)off < b || !std::strcmp(nm, "cand_cap")));
+                        if (!std::strcmp(nm, "cand_cap") && off >= 0) CHECK(off >= 64);
                       }
                   }
                 }
