@@ -72,3 +72,17 @@ def transfer_target_ref(y_pred: np.ndarray, thresh=0, n_points: int = 64, as_shi
     """utils/metrics.py:102-109: [N,H,W,L] -> float64 [N, 2L] (x0,y0,x1,y1,...)."""
     return np.array([transfer_xy_coord_ref(y_pred[i], n_points, thresh, as_shipped)
                      for i in range(y_pred.shape[0])], dtype=np.float64)
+
+
+def topn_gap_rel(maps: np.ndarray, n: int) -> np.ndarray:
+    """maps [HW, L] -> [L]: relative gap (v_n - v_{n+1}) / v_n between the n-th and (n+1)-th largest values of every
+    channel.  A top-n centroid SELECTS pixels: where two evaluations of the network disagree by more than this gap at
+    the n-th place they may select different pixels, and the coordinates then differ by the selection, not by rounding
+    (tests/test_gpu_baseline_configs.py calls such (face, class) pairs undetermined).  Checker helper, not a
+    restatement of reference code."""
+    hw = maps.shape[0]
+    part = np.partition(maps, hw - n - 1, axis=0)[hw - n - 1:]      # the n + 1 largest, the smallest of them first
+    vn1 = part[0]
+    vn = np.partition(part[1:], 0, axis=0)[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (vn - vn1) / vn
