@@ -76,14 +76,40 @@ __device__ __forceinline__ void insert_candidates(unsigned long long& list, unsi
   }
 }
 
+// The same for 64 < n <= 128 (the reference's own sweep decodes n = k*k up to 81, utils/metrics.py:130-133): the list
+// takes two registers per lane, ranks 0..63 in `l0` and 64..127 in `l1`; an insertion shifts both, the last entry of
+// `l0` carrying into lane 0 of `l1`.  tau = entry n-1 (in `l1`).
+__device__ __forceinline__ void insert_candidates_wide(unsigned long long& l0, unsigned long long& l1,
+                                                       unsigned long long& tau, unsigned long long cand, int n, int lane) {
+  unsigned long long mask = __ballot(cand > tau);
+  while (mask) {
+    const int src = __builtin_ctzll(mask);
+    const unsigned long long k = readlane64(cand, src);
+    if (lane == src) cand = 0;
+    const int pos = __builtin_popcountll(__ballot(l0 > k)) + __builtin_popcountll(__ballot(l1 > k));
+    const unsigned long long carry = readlane64(l0, 63);
+    const unsigned long long up0 = shfl_up64(l0, lane), up1 = shfl_up64(l1, lane);
+    if (pos < 64) {  // wave-uniform
+      l0 = (lane < pos) ? l0 : (lane == pos ? k : up0);
+      l1 = lane == 0 ? carry : up1;
+    } else {
+      const int q = pos - 64;
+      l1 = (lane < q) ? l1 : (lane == q ? k : up1);
+    }
+    if (lane + 64 >= n) l1 = 0;
+    tau = readlane64(l1, n - 65);
+    mask = __ballot(cand > tau);
+  }
+}
+
 // utils/metrics.py:69-77 on a finished list: float32 sum in ascending value order (= list lanes n-1 .. 0),
 // float64 index-weighted sums, reject when hsum / n_points <= thresh.
 __device__ __forceinline__ void finish_topn(unsigned long long list, int n_points, int w, float thresh, int lane,
-                                            double* out) {
+                                            double* out, unsigned long long list_hi = 0ull) {
   float hsum = 0.f;
   double i0 = 0.0, i1 = 0.0;
   for (int i = n_points - 1; i >= 0; --i) {
-    const unsigned long long k = readlane64(list, i);
+    const unsigned long long k = i >= 64 ? readlane64(list_hi, i - 64) : readlane64(list, i);
     if (k == 0ull) continue;
     const float hv = from_order_bits((unsigned)(k >> 32));
     const unsigned idx = (unsigned)k;
@@ -99,7 +125,7 @@ __device__ __forceinline__ void finish_topn(unsigned long long list, int n_point
   }
 }
 
-template <int MODE, int CPW>
+template <int MODE, int CPW, bool WIDE = false>
 __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
   if (a.gate && *a.gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [PT][LS]
@@ -114,12 +140,14 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
 
   double s0[CPW], sx[CPW], sy[CPW];                 // ALL
   unsigned long long list[CPW], tau[CPW];           // TOPN
+  unsigned long long list_hi[WIDE ? CPW : 1];       // TOPN, 64 < n <= 128: ranks 64..127
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
     if (MODE == FLM_DECODE_ALL) {
       s0[i] = 0.0; sx[i] = 0.0; sy[i] = 0.0;
     } else {
       list[i] = 0ull; tau[i] = 0ull;
+      if (WIDE) list_hi[i] = 0ull;
     }
   }
 
@@ -196,7 +224,10 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
           const float hv = tile[lane * LS + c];
           const unsigned long long key =
               pvalid ? (((unsigned long long)order_bits(hv) << 32) | (unsigned)pix) : 0ull;
-          if (__any(key > tau[i])) insert_candidates(list[i], tau[i], key, a.n_points, lane);
+          if (__any(key > tau[i])) {
+            if constexpr (WIDE) insert_candidates_wide(list[i], list_hi[i], tau[i], key, a.n_points, lane);
+            else insert_candidates(list[i], tau[i], key, a.n_points, lane);
+          }
         }
       }
     }
@@ -233,12 +264,13 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
     for (int i = 0; i < CPW; ++i) {
       const int c = c_first + i;
       if (c < L && lane < a.n_points) part[(size_t)c * a.n_points + lane] = list[i];
+      if (WIDE && c < L && lane + 64 < a.n_points) part[(size_t)c * a.n_points + 64 + lane] = list_hi[i];
     }
   }
 }
 
 // one wave per (face, landmark)
-template <int MODE>
+template <int MODE, bool WIDE = false>
 __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
   if (a.gate && *a.gate == 0) return;
   const int lane = threadIdx.x;
@@ -264,6 +296,21 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
     const unsigned long long* part =
         reinterpret_cast<const unsigned long long*>(a.part) + (size_t)face * a.chunks * L * a.n_points;
     unsigned long long list = 0ull, tau = 0ull;
+    if constexpr (WIDE) {  // 64 < n <= 128: a chunk's list arrives in two batches of up to 64 keys
+      unsigned long long list_hi = 0ull;
+      for (int s = 0; s < a.chunks; ++s)
+        for (int r0 = 0; r0 < a.n_points; r0 += 64) {
+          const unsigned long long cand = r0 + lane < a.n_points ? part[((size_t)s * L + c) * a.n_points + r0 + lane] : 0ull;
+          if (__any(cand > tau)) insert_candidates_wide(list, list_hi, tau, cand, a.n_points, lane);
+        }
+      if (a.tau_out) {
+        const unsigned long long k = readlane64(list_hi, a.n_points - 65);
+        if (lane == 0) a.tau_out[(size_t)face * L + c] = k ? from_order_bits((unsigned)(k >> 32)) : -3.402823466e38f;
+        return;
+      }
+      finish_topn(list, a.n_points, a.w, a.thresh, lane, out, list_hi);
+      return;
+    }
     // 64 / n_points chunk lists are merged per pass (lane -> (chunk offset, rank))
     const int per = 64 / a.n_points;
     for (int s0 = 0; s0 < a.chunks; s0 += per) {
@@ -547,8 +594,8 @@ int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, in
     set_error("decode: map too large");
     return FLM_ERR_SHAPE;
   }
-  if (mode == FLM_DECODE_TOPN && (n_points < 1 || n_points > 64)) {
-    set_error("decode: top-n mode supports 1 <= n_points <= 64 (got %d)", n_points);
+  if (mode == FLM_DECODE_TOPN && (n_points < 1 || n_points > 128)) {
+    set_error("decode: top-n mode supports 1 <= n_points <= 128 (got %d)", n_points);
     return FLM_ERR_UNSUPPORTED;
   }
   if (mode != FLM_DECODE_ALL && mode != FLM_DECODE_TOPN) {
@@ -578,6 +625,11 @@ int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, in
     else decode_partial_kernel<FLM_DECODE_ALL, 24><<<grid, 256, lds, s>>>(a);
     FLM_LAUNCH_CHECK("decode_partial_kernel");
     decode_merge_kernel<FLM_DECODE_ALL><<<dim3(l, n), 64, 0, s>>>(a);
+  } else if (n_points > 64) {  // two list registers per lane (the reference's sweep reaches n = 81)
+    if (small) decode_partial_kernel<FLM_DECODE_TOPN, 17, true><<<grid, 256, lds, s>>>(a);
+    else decode_partial_kernel<FLM_DECODE_TOPN, 24, true><<<grid, 256, lds, s>>>(a);
+    FLM_LAUNCH_CHECK("decode_partial_kernel");
+    decode_merge_kernel<FLM_DECODE_TOPN, true><<<dim3(l, n), 64, 0, s>>>(a);
   } else {
     if (small) decode_partial_kernel<FLM_DECODE_TOPN, 17><<<grid, 256, lds, s>>>(a);
     else decode_partial_kernel<FLM_DECODE_TOPN, 24><<<grid, 256, lds, s>>>(a);

@@ -794,7 +794,8 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   // a 1x1 classifier on the fc grid (score5: K = 4096 into one N tile) splits at EVERY batch, always 8 ways beyond 16
   // faces: with a tile cap its sums changed at 129 faces, the only layer whose bits depended on the batch beyond the
   // documented brackets (tools/debug_batch_invariance.py)
-  const bool narrow_1x1 = d.kh * d.kw == 1 && d.cin / bke >= 32 && d.cout <= BN;
+  // (fp32, the parity path, only: in bf16 at batch 512 the eight partial planes cost 0.05 ms the layer does not have)
+  const bool narrow_1x1 = !d.bf16 && d.kh * d.kw == 1 && d.cin / bke >= 32 && d.cout <= BN;
   const int tile_cap = narrow_1x1 ? 0x7fffffff : ((d.cout >= 1024 || few_faces) ? 256 : 64);  // the wide fc layers keep splitting until they fill the chip
   if (d.splitk_ws && !d.res && stride == 1 && tiles <= tile_cap && (!d.pool || (a.M & 3) == 0) &&
       (d.kh * d.kw == 1 ? a.cpt >= 32 : (a.cpt >= 4 && (d.cout >= 1024 || tiles <= 16 * faces || few_faces))) &&

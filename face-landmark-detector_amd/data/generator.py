@@ -2,9 +2,11 @@
 
 Same signature, argument meaning and errors.  cv2 is not a dependency: files are decoded
 with PIL into BGR (what cv2.imread returns), and an image whose size differs from
-(width, height) is resampled on the GPU with the build-defined fp32 bilinear of
-`flm_crop_resize` (cv2.resize's fixed-point INTER_LINEAR cannot be pinned without cv2);
-for crops already at model size -- the hot path -- the resize is the identity, as in cv2.
+(width, height) is resampled on the GPU by `flm_crop_resize`: OpenCV's 8-bit INTER_LINEAR
+restated in integer fixed point (11-bit weights, the exact 2x downscale as INTER_AREA), bit-equal
+to `oracle/warp_ref.resize_u8_ref`; parity with the cv2 binary itself is unpinned (cv2 is not
+installable here).  For crops already at model size -- the hot path -- the resize is the identity,
+as in cv2.
 """
 from __future__ import annotations
 

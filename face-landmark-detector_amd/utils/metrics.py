@@ -8,7 +8,8 @@ EVERY call decodes with n_points=4, thresh=0, whatever the caller passed.  Drop-
   * a call that passes `n_points` / `thresh` explicitly gets what it asked for (the reference would
     silently ignore the arguments) and a one-time warning says so;
   * `as_shipped=True` forces the reference's behaviour, `as_shipped=False` the documented one.
-Device limits: 1 <= n_points <= 64 in top-n mode, <= 96 landmarks per map.
+Device limits: 1 <= n_points <= 128 in top-n mode (the reference's own sweep reaches 81, utils/metrics.py:130-133),
+<= 96 landmarks per map.
 """
 from __future__ import annotations
 

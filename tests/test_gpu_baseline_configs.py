@@ -272,9 +272,11 @@ def test_config3_batch512_bf16(flm, weights68):
     d = np.linalg.norm(lm0 - lm0_32, axis=-1)
     print("all 512 faces, bf16 vs fp32 HIP, all-pixel centroid: NME %.3g, max %.3g px" % (d.mean() / 256, d.max()))
     assert d.mean() / 256 < 2e-4 and d.max() < 0.25
-    # top-4 on random-weight maps: a bf16 rounding moves pixels in and out of the selection, so only the rate of
-    # identical selections is recorded, and that every landmark is a point of the grid
+    # top-4 on random-weight maps: a bf16 rounding moves pixels in and out of the selection, so what is gated is the rate
+    # of (near-)identical selections, with a floor two points under the measured rate, and that every landmark is a point
+    # of the grid
     lm4_32 = m32.forward_device(xd, "landmarks", n_points=4).cpu().numpy()
     close = np.abs(lm4 - lm4_32).max(-1) < 0.5
     print("top-4: %.1f %% of the 512x68 landmarks within 0.5 px of the fp32 path" % (100 * close.mean()))
+    assert close.mean() >= 0.899            # measured 91.9 %; the floor is that minus 2 points
     assert (lm4 >= 0).all() and lm4[..., 0].max() <= 263 and lm4[..., 1].max() <= 263

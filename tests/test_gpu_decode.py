@@ -95,10 +95,25 @@ def test_negative_and_tiny_maps(M):
         assert np.array_equal(got, exp, equal_nan=True)
 
 
+def test_wide_lists_n_up_to_128(M):
+    """n_points beyond 64 (the reference's sweep calls transfer_target with n = k*k up to 81, utils/metrics.py:130-133):
+    two list registers per lane; bit-equal to the oracle, ties included, for maps of 68 and of 80 channels (the
+    17- and 24-channels-per-wave kernels), a map smaller than n, and the forward's landmark mode."""
+    rng = np.random.default_rng(9)
+    for shape in ((2, 40, 37, 68), (1, 24, 24, 80), (1, 8, 9, 3)):
+        y = rng.random(shape, dtype=np.float32)
+        y[0, :3, :5, 0] = 0.75          # ties at and around the n-th place
+        for n in (65, 81, 100, 128):
+            with np.errstate(all="ignore"):
+                exp = decode_ref.transfer_target_ref(y, 0.2, n)
+            got = M.transfer_target(y, 0.2, n)
+            assert np.array_equal(got, exp, equal_nan=True), (shape, n)
+
+
 def test_unsupported_n_points_raises(M):
     from flm_amd._lib import FlmError
     with pytest.raises(FlmError):
-        M.transfer_target(np.zeros((1, 16, 16, 2), np.float32), 0, 65)
+        M.transfer_target(np.zeros((1, 16, 16, 2), np.float32), 0, 129)
 
 
 def test_full_size_properties(M):
