@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned cand_order_bits(float v) {
   return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
 
-// Developer ablations (tools/ablate_up3.py builds variants with -DFLM_ABLATE=<mask>; results are wrong, only timings
+// Developer ablations (tools/ab_variants.py builds variants with -DFLM_ABLATE=<mask>; results are wrong, only timings
 // mean anything): 1 no candidate test / stores (part 3), 2 no normalisation (part 2), 4 no max / exp (part 1),
 // 8 no MFMAs, 16 no weight ring (loads, LDS stores, barriers); cand8 kernel: 32 prologue only, 64 no end-of-phase
 // wait + barrier, 128 no hit loop, 256 no softmax / threshold ops, 512 no MFMAs, 1024 no LDS-DMA.  0 in every shipped build.
@@ -668,7 +668,7 @@ static int convt_rows_per_wg(int xblocks, int s, int wg_slots, int forced = 0) {
 // =====================================================================================================================
 // up3 in landmark mode (epilogue 3) for the 68-class model: a kernel of its own (`cand8`), bf16 and fp32.
 //
-// What the generic kernel above spends its time on in this mode (tools/ablate_up3.py, bf16 batch 512: 2.63 ms): the
+// What the generic kernel above spends its time on in this mode (round-1 ablations with -DFLM_ABLATE, bf16 batch 512: 2.63 ms): the
 // weight ring alone -- global -> registers -> ds_write -> barrier, three chunks per phase, 13.6 GB per launch out of L2 --
 // takes 1.40 ms with everything else compiled out; the ten threshold reads per phase each expose an LDS round trip; the
 // candidate code, inlined at 160 sites, pushes the loop past the instruction cache (68 KB); and every workgroup reloads

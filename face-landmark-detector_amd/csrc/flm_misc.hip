@@ -334,8 +334,9 @@ int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, in
 //   fx      = (float)((x + 0.5) * scale_x - 0.5);  sx = floor(fx);  fx -= sx    (product and sum in double)
 //   sx < 0 -> sx = 0, fx = 0;   sx >= cw-1 -> sx = cw-1, fx = 0
 //   a1 = (int)rint(fx * 2048),  a0 = (int)rint((1.f - fx) * 2048)               (11-bit weights, ties to even)
-//   row r:  h_r = S[r][sx]*a0 + S[r][min(sx+1, cw-1)]*a1                        (int32; rows sy and min(sy+1, ch-1))
-//   out = (((b0 * (h_0 >> 4)) >> 16) + ((b1 * (h_1 >> 4)) >> 16) + 2) >> 2      (b0, b1: the same weights along y)
+//   row r:  h_r = S[r][sx]*a0 + S[r][min(sx+1, cw-1)]*a1                        (int32; rows clamp(sy), clamp(sy+1))
+//   out = (((b0 * (h_0 >> 4)) >> 16) + ((b1 * (h_1 >> 4)) >> 16) + 2) >> 2      (b0, b1: the weights of the UNCLAMPED
+//                                                                                 fy: only the row indices clamp)
 //   exact 2x downscale in both axes (cw == 2*ow, ch == 2*oh): cv2 switches INTER_LINEAR to the area average
 //   out = (S[2y][2x] + S[2y][2x+1] + S[2y+1][2x] + S[2y+1][2x+1] + 2) >> 2.
 __device__ __forceinline__ void resize_coef(int d, double scale, int n_src, int& s0, int& s1, int& w0, int& w1) {
@@ -346,6 +347,19 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int n_src, int&
   if (s >= n_src - 1) { s = n_src - 1; f = 0.f; }
   s0 = s;
   s1 = min(s + 1, n_src - 1);
+  w0 = (int)rintf((1.f - f) * 2048.f);
+  w1 = (int)rintf(f * 2048.f);
+}
+
+// Along y OpenCV clamps only the ROW INDICES (clip(sy + k, 0, h)) and keeps the split weights of the unclamped
+// position: on the first / last output rows of an upscale both rows are the border row, weighted b0 and b1 separately
+// -- floor(b0*v >> 16) + floor(b1*v >> 16) is not always (2048*v) >> 16, so folding the weights there is off by one LSB.
+__device__ __forceinline__ void resize_coef_y(int d, double scale, int n_src, int& s0, int& s1, int& w0, int& w1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  const int s = (int)floorf(f);
+  f -= (float)s;
+  s0 = min(max(s, 0), n_src - 1);
+  s1 = min(max(s + 1, 0), n_src - 1);
   w0 = (int)rintf((1.f - f) * 2048.f);
   w1 = (int)rintf(f * 2048.f);
 }
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
     }
     int x0, x1, a0, a1, y0, y1, b0, b1;
     resize_coef(x, scale_x, cw, x0, x1, a0, a1);
-    resize_coef(y, scale_y, ch, y0, y1, b0, b1);
+    resize_coef_y(y, scale_y, ch, y0, y1, b0, b1);
     const uint8_t* r0 = src + (size_t)y0 * pitch;
     const uint8_t* r1 = src + (size_t)y1 * pitch;
 #pragma unroll

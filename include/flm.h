@@ -205,8 +205,8 @@ int64_t flm_fcn8_workspace_offset_opts(const char* name, int n, int h, int w, in
                                        int out_mode, int decode_mode, int n_points, const flm_forward_opts* opts);
 
 /* One named Conv2D layer of the model in isolation ("enc2".."enc5" with BN+ReLU+pool fused,
- * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  Used by
- * tools/debug_layer.py to run and time one layer in isolation. */
+ * "fc6", "fc7", "score5", "score4", "score3"): x_dev float32 [n,h,w,Cin] -> y_dev.  For tests and
+ * developer tools that run or time one layer in isolation. */
 int flm_fcn8_run_layer(flm_stream_t stream, const void* packed_dev, const char* layer, const void* x_dev,
                        void* y_dev, int n, int h, int w, int n_classes, int dtype);
 

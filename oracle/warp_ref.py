@@ -121,6 +121,19 @@ def _resize_coef(n_dst: int, n_src: int):
     return s, np.minimum(s + 1, n_src - 1), w0, w1
 
 
+def _resize_coef_y(n_dst: int, n_src: int):
+    """The same along y, where OpenCV clamps only the row indices (`clip(sy + k, 0, h)`) and keeps the split weights of
+    the unclamped position: on the border rows of an upscale both taps read the border row, weighted b0 and b1."""
+    scale = np.float64(1.0) / (np.float64(n_dst) / np.float64(n_src))
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    w0 = np.rint((f32(1) - f) * f32(2048)).astype(np.int64)
+    w1 = np.rint(f * f32(2048)).astype(np.int64)
+    return np.clip(s, 0, n_src - 1), np.clip(s + 1, 0, n_src - 1), w0, w1
+
+
 def resize_u8_ref(src: np.ndarray, oh: int, ow: int) -> np.ndarray:
     """`cv2.resize(src, (ow, oh))` for uint8 [h,w,c] with the default INTER_LINEAR, as OpenCV's generic code computes
     it (data/generator.py:53, prediction.py:82).  Integer arithmetic throughout:
@@ -132,7 +145,7 @@ def resize_u8_ref(src: np.ndarray, oh: int, ow: int) -> np.ndarray:
     if cw == 2 * ow and ch == 2 * oh:
         return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
     x0, x1, a0, a1 = _resize_coef(ow, cw)
-    y0, y1, b0, b1 = _resize_coef(oh, ch)
+    y0, y1, b0, b1 = _resize_coef_y(oh, ch)
     hrow = s[:, x0] * a0[None, :, None] + s[:, x1] * a1[None, :, None]            # [ch, ow, c]
     h0, h1 = hrow[y0] >> 4, hrow[y1] >> 4
     out = (((b0[:, None, None] * h0) >> 16) + ((b1[:, None, None] * h1) >> 16) + 2) >> 2

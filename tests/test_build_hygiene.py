@@ -62,5 +62,6 @@ def test_vgpr_budgets(metadata):
             assert vgpr <= 256, (name, vgpr)            # 2 workgroups of 4 waves per CU
         if "convt_kernelILi5ELi17ELb0" in name or "convt_kernelILi5ELi9ELb1" in name:
             assert vgpr <= 256, (name, vgpr)
-        if "decode_partial_kernelILi1ELi17" in name:
-            assert vgpr <= 168, (name, vgpr)            # >= 3 waves per SIMD for the streaming decode
+        if "decode_partial_kernelILi1ELi17ELb0" in name:
+            assert vgpr <= 168, (name, vgpr)            # >= 3 waves per SIMD for the streaming decode (n <= 64; the
+                                                        # two-register lists of 64 < n <= 128 take 190: 2 waves)

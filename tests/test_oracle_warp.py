@@ -74,6 +74,38 @@ def test_resize_u8_fixed_point_properties():
     assert s0.tolist() == [0, 0, 0, 1] and w1.tolist() == [0, 512, 1536, 0] and (w0 + w1 == 2048).all()
 
 
+def test_resize_u8_border_rows_keep_split_weights():
+    """Along y OpenCV's generic 8-bit resize clamps only the row indices (`clip(sy + k, 0, h)`, imgproc/resize.cpp) and
+    keeps the split weights of the unclamped position, while along x it folds them (fx = 0 at the border).  On the
+    first and last output rows of an upscale both taps therefore read the border row with weights b0 | b1, and
+    floor(b0*v >> 16) + floor(b1*v >> 16) differs from (2048*v) >> 16 by one LSB for some horizontal sums v.  The border
+    rows are written out by hand here, independently of the vectorised restatement (the x weights are taken from it)."""
+    rng = np.random.default_rng(12)
+    for (h, oh) in ((96, 256), (150, 256), (200, 256)):
+        img = rng.integers(0, 256, (h, h, 1), dtype=np.uint8)
+        got = warp_ref.resize_u8_ref(img, oh, oh)
+        x0, x1, a0, a1 = warp_ref._resize_coef(oh, h)
+        scale = 1.0 / (oh / h)
+        differs_from_folded = 0
+        for dy in (0, 1, oh - 2, oh - 1):
+            f = np.float32((dy + 0.5) * scale - 0.5)
+            sy = int(np.floor(f))
+            fy = np.float32(f - np.float32(sy))
+            b1 = int(np.rint(fy * np.float32(2048)))
+            b0 = int(np.rint((np.float32(1) - fy) * np.float32(2048)))
+            r0, r1 = min(max(sy, 0), h - 1), min(max(sy + 1, 0), h - 1)
+            for x in range(oh):
+                h0 = int(img[r0, x0[x], 0]) * int(a0[x]) + int(img[r0, x1[x], 0]) * int(a1[x])
+                h1 = int(img[r1, x0[x], 0]) * int(a0[x]) + int(img[r1, x1[x], 0]) * int(a1[x])
+                exp = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+                assert int(got[dy, x, 0]) == exp, (h, oh, dy, x)
+                if r0 == r1:
+                    differs_from_folded += exp != ((((2048 * (h0 >> 4)) >> 16) + 2) >> 2)
+        assert differs_from_folded > 0          # the case the folded rule got wrong is really exercised
+    s0, s1, w0, w1 = warp_ref._resize_coef_y(4, 2)
+    assert s0.tolist() == [0, 0, 0, 1] and s1.tolist() == [0, 1, 1, 1] and w1.tolist() == [1536, 512, 1536, 512]
+
+
 def test_similarity_skips_rejected_landmarks():
     rng = np.random.default_rng(0)
     p = rng.uniform(10, 200, (1, 10, 2))

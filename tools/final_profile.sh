@@ -26,6 +26,6 @@ for p in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_
 done
 hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak > /dev/null 2>&1 && timeout -k 10 200 /tmp/mfma_peak > $O/mfma_peak.txt 2>&1
 echo peak done
-# the raw counter CSVs are large: keep what tools/pmc_report2.py reads
+# the raw counter CSVs are large: keep what tools/pmc_report.py reads
 find $O -name "*.csv" -size +20M -delete
 ls $O
