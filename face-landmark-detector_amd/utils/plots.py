@@ -44,15 +44,21 @@ def _resize_nearest(img, w, h):
     return img[ys][:, xs]
 
 
-def _linear_coef(n_dst, n_src):
+def _linear_coef(n_dst, n_src, along_y=False):
+    """Tap indices and 11-bit weights of OpenCV's 8-bit INTER_LINEAR.  Along x a position outside [0, n_src - 1] folds
+    onto the border pixel with weights 2048 | 0; along y only the row indices clamp and the split weights stay."""
     scale = np.float64(1.0) / (np.float64(n_dst) / np.float64(n_src))
     f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
     f = (f - s.astype(np.float32)).astype(np.float32)
-    low, high = s < 0, s >= n_src - 1
-    s = np.where(low, 0, np.where(high, n_src - 1, s))
-    f = np.where(low | high, np.float32(0), f).astype(np.float32)
-    return (s, np.minimum(s + 1, n_src - 1), np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64),
+    if along_y:
+        s0, s1 = np.clip(s, 0, n_src - 1), np.clip(s + 1, 0, n_src - 1)
+    else:
+        low, high = s < 0, s >= n_src - 1
+        s0 = np.where(low, 0, np.where(high, n_src - 1, s))
+        s1 = np.minimum(s0 + 1, n_src - 1)
+        f = np.where(low | high, np.float32(0), f).astype(np.float32)
+    return (s0, s1, np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64),
             np.rint(f * np.float32(2048)).astype(np.int64))
 
 
@@ -70,7 +76,7 @@ def _resize_linear_u8(img, w, h):
         out = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
     else:
         x0, x1, a0, a1 = _linear_coef(w, sw)
-        y0, y1, b0, b1 = _linear_coef(h, sh)
+        y0, y1, b0, b1 = _linear_coef(h, sh, along_y=True)
         hrow = s[:, x0] * a0[None, :, None] + s[:, x1] * a1[None, :, None]
         out = (((b0[:, None, None] * (hrow[y0] >> 4)) >> 16) + ((b1[:, None, None] * (hrow[y1] >> 4)) >> 16) + 2) >> 2
     out = out.astype(np.uint8)
