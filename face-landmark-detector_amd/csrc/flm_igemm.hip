@@ -92,7 +92,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   // flm_igemm_bf16.hip.  The loop over the pair kept set-up values alive across a k-loop that has no register to spare.)
   constexpr bool PAIR = (MMAP == 2) && !TWO;
   const int mslots = PAIR ? (a.mtiles + 1) / 2 : a.mtiles;
-  const int mslot = L % mslots, nt = L / mslots;
+  int mslot = L % mslots, nt = L / mslots;
+  if (MMAP == 2 && TWO && (a.ntiles & 7) == 0) {
+    // An XCD is dealt the logical ids of ntiles / 8 weight panels x all tiles, in order.  Panel-major, heaviest first
+    // inside each panel, that order starts the last panel's heavy tiles late: on the batch-64 tile weights
+    // (49,49,49,49,42,...,20 taps) the list schedule ends at 84 units where 66 is ideal.  Rank-major across the XCD's
+    // panels it is longest-first: 69, what the pairing of the other form reaches by construction.
+    const int ppx = a.ntiles >> 3, per_xcd = mslots * ppx;
+    const int xcd = L / per_xcd, l = L - xcd * per_xcd;
+    mslot = l / ppx;
+    nt = xcd * ppx + (l - mslot * ppx);
+  }
   const int n0 = nt * BN;
   const int npass = (PAIR && mslot != a.mtiles - 1 - mslot) ? 2 : 1;
   int pair_mt[2] = {mslot, mslot};
