@@ -205,6 +205,35 @@ def test_config2_batch64_fp32_against_the_oracle(flm, weights68):
         assert e_dec <= PX and over == 0, (npts, e_dec, over)     # the north_star bar, on every determined pair
 
 
+@pytest.mark.parametrize("wseed,xseed", [(5, 11), (9, 23)])
+def test_top4_bar_holds_for_other_weights_and_crops(flm, wseed, xseed):
+    """The 1e-4 px bar on the as-shipped top-4 decode is not a property of one seed: other synthetic weight sets and
+    crops, 16 faces each (1,088 pairs), every determined pair within 1e-4 px of the float64 oracle."""
+    from flm_amd.networks import LANDMARKS_MODELS
+    from flm_amd.weights import synth_fcn8_weights
+    from oracle import decode_ref, fcn_ref
+    n, c = 16, 68
+    w = synth_fcn8_weights(c, seed=wseed)
+    crops = np.random.default_rng(xseed).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    model = LANDMARKS_MODELS["fcn_8"](c, input_height=256, input_width=256)
+    model.load_weights(w)
+    lm = model.forward_device(torch.from_numpy(crops).cuda(), "landmarks", n_points=4).cpu().numpy()
+    worst, undet = 0.0, 0
+    for lo in range(0, n, 8):
+        x_ref = np.stack([fcn_ref.get_image_array_ref(im) for im in crops[lo:lo + 8]])
+        p64 = fcn_ref.fcn8_predict_ref(x_ref, w, torch.float64)
+        for i in range(8):
+            det = decode_ref.topn_gap_rel(p64[i], 4) > GAP_REL
+            with np.errstate(all="ignore"):
+                ref = decode_ref.transfer_target_ref(p64[i].astype(np.float32).reshape(1, 264, 264, c), 0, 4).reshape(c, 2)
+            e = np.abs(lm[lo + i] - ref).max(-1)
+            worst = max(worst, float(e[det].max()))
+            undet += int((~det).sum())
+    print("weights seed %d, crops seed %d: top-4 max err %.3g px over the determined pairs (%d undetermined of %d)"
+          % (wseed, xseed, worst, undet, n * c))
+    assert worst <= PX and undet <= 0.01 * n * c
+
+
 def test_config2_faces_do_not_depend_on_the_batch_beyond_the_split_k_brackets(flm, weights68):
     """A face's bits are the same in a batch of 20 and in the batch of 64 (both beyond the split-K brackets, which end
     at 16 faces): tap skipping in fc6's position-major tiles drops only products with zero padding."""
