@@ -26,6 +26,7 @@ SOURCES = [
     "flm_igemm_bf16.hip",
     "flm_conv3_halo.hip",
     "flm_score1x1.hip",
+    "flm_tail_bf16.hip",
     "flm_convt.hip",
     "flm_decode.hip",
     "flm_misc.hip",

@@ -270,6 +270,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::score1x1_enable(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "bf16_fused_tail")) {  // score3 + up4 as one launch (flm_tail_bf16.hip): 0 off, 1 on.  Same bits
+    flm::tail_fused_enable(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_conv3_halo")) {  // halo-resident 3x3 kernel for 64-channel inputs: 0 off, 1 auto, 2 always
     flm::conv3_halo_enable(value);
     return FLM_OK;
@@ -589,9 +593,14 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   { ProfScope ps(s, "score4");
   rc = conv_layer(s, blob, L.score4, f[3], fuse4, n, h4, w4, 0, 0, 0, dtype, 1); }
   if (rc) return rc;
+  // (bf16, 68 classes: score3 and up4 run as ONE launch after up5, flm_tail_bf16.hip -- same bits)
+  const bool fuse_seg = bf && L.g.C == 68 && L.score3.cin == 256 && L.score3.kh == 1;
+  int fused_seg = 0;
+  if (!fuse_seg) {
   { ProfScope ps(s, "score3");
   rc = conv_layer(s, blob, L.score3, f[2], seg, n, h3, w3, 0, 0, 0, dtype, 1); }
   if (rc) return rc;
+  }
   // up5 (fcn.py:104) + crop + Add (fcn.py:110-112), in place on fuse4
   t.x = score5; t.wf = blob + L.up5; t.skip = fuse4; t.y = fuse4;
   t.hi = h5; t.wi = w5; t.ho = h4; t.wo = w4; t.s = 2; t.ldy = L.g.Cp; t.epilogue = 0;
@@ -599,11 +608,26 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
   rc = launch_convt(s, t); }
   if (rc) return rc;
   // up4 (fcn.py:114) + crop + Add (fcn.py:118-119), in place on seg ("seg_feats")
+  if (fuse_seg) {
+    ProfScope ps(s, "seg_fused");
+    fused_seg = launch_seg_fused_bf16(s, fuse4, blob + L.up4, f[2], blob + L.score3.w,
+                                      reinterpret_cast<const float*>(blob + L.score3.scale),
+                                      reinterpret_cast<const float*>(blob + L.score3.shift), seg, n, h4, w4, L.g.C, L.g.Cp,
+                                      L.g.G, L.score3.cin, L.score3.coutpad);
+    if (fused_seg < 0) return fused_seg;
+  }
+  if (fuse_seg && !fused_seg) {  // (knob off, or a shape the fused kernel leaves alone: the two-launch form)
+    ProfScope ps(s, "score3");
+    rc = conv_layer(s, blob, L.score3, f[2], seg, n, h3, w3, 0, 0, 0, dtype, 1);
+    if (rc) return rc;
+  }
   t.x = fuse4; t.wf = blob + L.up4; t.skip = seg; t.y = seg;
   t.hi = h4; t.wi = w4; t.ho = h3; t.wo = w3;
+  if (!fused_seg) {
   { ProfScope ps(s, "up4");
   rc = launch_convt(s, t); }
   if (rc) return rc;
+  }
   }  // !fcn32
   // last upsampling + softmax (networks/utils.py:30) / argmax (prediction.py:209):
   //   fcn_8 : Conv2DTranspose(16x16, s8) on seg_feats  (fcn.py:121)

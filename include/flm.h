@@ -238,6 +238,9 @@ int flm_profile_filter(const char* layer);
  *   "bf16_conv3_halo"       0 off | 1 auto (default) | 2 always: halo-resident 3x3 kernel for 64-channel inputs
  *   "bf16_score1x1"         1 (default): 1x1 classifiers on 256-channel bf16 maps (score4, score3) run the kernel that
  *                           keeps the weights in registers (csrc/flm_score1x1.hip); 0: the implicit GEMM.  Same bits
+ *   "bf16_fused_tail"       1 (default): seg_feats = crop(up4(fuse4)) + score3(f3) is ONE launch in the bf16 configuration
+ *                           of the 68-class models (csrc/flm_tail_bf16.hip); 0: score3, then up4 with the skip add.
+ *                           Same bits
  *   "up3_cand8"             bit 0: the bf16 candidate launch of the last transposed conv runs the 8-wave kernel
  *                           (csrc/flm_convt.hip, up3_cand8_kernel); bit 2: its 4-wave x 2-workgroup shape; default 1;
  *                           0: the generic kernel.  Same keys either way.  Bit 1 (an fp32 form of that kernel) is

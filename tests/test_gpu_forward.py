@@ -276,6 +276,7 @@ def test_bf16_score_kernel_equals_implicit_gemm(flm, weights68):
         xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
         outs = {}
         try:
+            _lib.check(lib.flm_set_tuning(b"bf16_fused_tail", 0), "set_tuning")   # (score3 as a launch of its own)
             for knob in (0, 1):
                 _lib.check(lib.flm_set_tuning(b"bf16_score1x1", knob), "set_tuning")
                 probs = model.forward_device(xd, "probs").cpu().numpy()
@@ -283,9 +284,36 @@ def test_bf16_score_kernel_equals_implicit_gemm(flm, weights68):
                 outs[knob] = (probs, inter)
         finally:
             _lib.check(lib.flm_set_tuning(b"bf16_score1x1", 1), "set_tuning")
+            _lib.check(lib.flm_set_tuning(b"bf16_fused_tail", 1), "set_tuning")
         for k in outs[0][1]:
             assert np.array_equal(outs[0][1][k], outs[1][1][k]), (k, n, h, w)
         assert np.array_equal(outs[0][0], outs[1][0]), (n, h, w)
+
+
+def test_bf16_fused_skip_stage_equals_the_two_launches(flm, weights68):
+    """flm_tail_bf16.hip: seg_feats = crop(up4(fuse4)) + score3(f3) in one launch against score3 followed by up4 with the
+    skip add -- seg_feats, the probabilities and the top-4 landmarks bit for bit; ragged widths (w/16 = 10: one slice of
+    10 pixels per row; 2; 32: two slices per row) and the headline shape."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    rng = np.random.default_rng(36)
+    for (n, h, w) in ((3, 96, 160), (5, 256, 256), (1, 32, 32), (2, 64, 512)):
+        model = LANDMARKS_MODELS["fcn_8"](68, input_height=h, input_width=w, dtype="bf16")
+        model.load_weights(weights68)
+        xd = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+        outs = {}
+        try:
+            for knob in (0, 1):
+                _lib.check(lib.flm_set_tuning(b"bf16_fused_tail", knob), "set_tuning")
+                probs = model.forward_device(xd, "probs").cpu().numpy()
+                seg = model.intermediate("seg_feats", n, "probs").cpu().numpy()
+                lm = model.forward_device(xd, "landmarks", n_points=4).cpu().numpy()
+                outs[knob] = (probs, seg, lm)
+        finally:
+            _lib.check(lib.flm_set_tuning(b"bf16_fused_tail", 1), "set_tuning")
+        for a, b, what in zip(outs[0], outs[1], ("probs", "seg_feats", "landmarks")):
+            assert np.array_equal(a, b), (what, n, h, w)
 
 
 def test_bf16_halo_conv_equals_implicit_gemm(flm, weights68):
