@@ -84,6 +84,8 @@ def layer_bf16(name, grid):
         return None          # enc3 / enc4 / enc5 share the instantiation: told apart by duration below
     if "up3_cand8_kernel" in name:
         return "up3"
+    if "seg_fused_bf16_kernel" in name:
+        return "seg_fused"
     if "convt_kernel" in name and (", 2, false>" in name):
         return "up3_sub"
     if "cand_merge" in name:
