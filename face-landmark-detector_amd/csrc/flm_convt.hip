@@ -84,7 +84,8 @@ __device__ __forceinline__ unsigned cand_order_bits(float v) {
 // Developer ablations (tools/ab_variants.py builds variants with -DFLM_ABLATE=<mask>; results are wrong, only timings
 // mean anything): 1 no candidate test / stores (part 3), 2 no normalisation (part 2), 4 no max / exp (part 1),
 // 8 no MFMAs, 16 no weight ring (loads, LDS stores, barriers); cand8 kernel: 32 prologue only, 64 no end-of-phase
-// wait + barrier, 128 no hit loop, 256 no softmax / threshold ops, 512 no MFMAs, 1024 no LDS-DMA.  0 in every shipped build.
+// wait + barrier, 128 no hit loop, 256 no softmax / threshold ops, 512 no MFMAs, 1024 no LDS-DMA, 2048 the branchy
+// per-piece form of the requests (results unchanged).  0 in every shipped build.
 #ifndef FLM_ABLATE
 #define FLM_ABLATE 0
 #endif
@@ -865,6 +866,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
   for (int k = 0; k < NDMA; ++k) dma_issue(0, wave + WAVES * k);
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
   __syncthreads();
+  // Whole-phase ring steps (NSTEP == 1: the bf16 8-wave shape): the byte offsets of this wave's NDMA pieces, for a leader
+  // phase (5 class tiles per k group) and for a short one (4), are computed ONCE; a piece the wave does not have repeats
+  // its first one (the same bytes to the same place).  The per-phase request is then two scalar selects and two adds per
+  // piece and NO branch: the general form above decides `i < np` per piece -- six scalar branches and ~90 scalar
+  // instructions per phase inside the slot-scheduled stream (round-3 ablation: 0.4 ms of the launch went with the requests).
+  int pieceL[NDMA], pieceS[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    const int i = wave + WAVES * k, i0 = wave;
+    pieceL[k] = (i < G * MT ? i : i0) * PIECE;
+    const int is_ = i < G * 4 ? i : i0;
+    pieceS[k] = ((is_ >> 2) * MT + (is_ & 3)) * PIECE;
+  }
+  auto dma_issue_fast = [&](int u, auto kc) __attribute__((always_inline)) {   // requests piece k of ring step u (phase u)
+    constexpr int k = decltype(kc)::value;
+    const int t = u < nph ? u : nph - 1;                 // (past the last phase: its own weights again, into the idle slot)
+    const int off = (t & 3) == 0 ? pieceL[k] : pieceS[k];
+    dma_piece(wsrd, ring_lds + (unsigned)((u & 1) * SLOT_BYTES + off), voff, (row0 * s + t) * C::PHASE_BYTES + off);
+  };
 
   f32x4 accA[NT][MT], accB[NT][MT];
 #pragma unroll
@@ -1065,7 +1085,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
       // the next step's pieces: requested in the first slots -- its ring slot has been free since this step's barrier,
       // and the requests then have the whole step to land
       if constexpr (IL < NDMA) {
-        if (u + 1 < nph * NSTEP && !(FLM_ABLATE & 1024)) dma_issue(u + 1, wave + WAVES * IL);
+        if constexpr (NSTEP == 1 && !(FLM_ABLATE & 2048)) {
+          if (!(FLM_ABLATE & 1024)) dma_issue_fast(u + 1, std::integral_constant<int, IL>{});
+        } else {
+          if (u + 1 < nph * NSTEP && !(FLM_ABLATE & 1024)) dma_issue(u + 1, wave + WAVES * IL);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
