@@ -654,7 +654,8 @@ def main():
                                  "traffic_bf16_latest.json")
         else:
             issued = fc6_issued_gflop(B)
-            roof = mfma_roofline("fc6", "igemm_kernel<f32,MMAP=2,RELU> (fc6: 7x7x256->4096 on 8x8, M=64*B, K=12544)",
+            roof = mfma_roofline("fc6", "igemm_kernel<f32,MMAP=2,RELU,TWO> (fc6: 7x7x256->4096 on 8x8, M=64*B, K=12544; LDS-DMA "
+                                        "operand ring, three-level accumulation)",
                                  roof_ms, B, peak, "traffic_latest.json",
                                  {"issued_tflops": issued / roof_ms, "frac_issued": issued / roof_ms / peak})
         rec = {

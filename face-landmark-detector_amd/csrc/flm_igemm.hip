@@ -32,7 +32,8 @@
 #include "flm_igemm_args.h"
 
 // Developer variants (tools/ab_variants.py builds the file with -DFLM_IGEMM_VAR=<mask>; 0 in every shipped build):
-// 1 no third accumulation level, 2 two fragment address registers + one v_xor per read instead of eight registers
+// 4 no vmcnt wait before the step's barrier, 8 no LDS-DMA requests in the k-loop, 16 no barrier (4 / 8 / 16: timing
+// ablations, results wrong), 1 no third accumulation level, 2 two fragment address registers + one v_xor per read instead of eight registers
 // (chunk (2t + lh) ^ swx = ((lh ^ swx) ^ 2t): group t's address is group 0's with bits 5-6 flipped; frees six registers,
 // costs 1.5 % of a layer).
 #ifndef FLM_IGEMM_VAR
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     FLM_MFMA4(afx0, afx1, bfx0, bfx1, y)                                                              \
     FLM_MFMA4(afx0, afx1, bfx0, bfx1, z)                                                              \
     FLM_MFMA4(afx0, afx1, bfx0, bfx1, w)                                                              \
-    __builtin_amdgcn_s_waitcnt(0x0f70);                                                               \
-    __syncthreads();                                                                                  \
+    if (!(FLM_IGEMM_VAR & 4)) __builtin_amdgcn_s_waitcnt(0x0f70);                                     \
+    if (!(FLM_IGEMM_VAR & 16)) __syncthreads();                                                       \
     /* third level, right behind the barrier: the second set holds the steps before this one; if this step opened */ \
     /* a new group they are a closed group */                                                         \
     if (!(FLM_IGEMM_VAR & 1) && g_prev != g_cur) {                                                    \
@@ -385,10 +386,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     {                                                                                                 \
       FLM_MFMA4(afy0, afy1, bfy0, bfy1, x)                                                            \
       FLM_READ_FRAGS(afx0, afx1, bfx0, bfx1, 0, (BUF) ^ 1)                                            \
-      FLM_DMA_A(0, BUF) FLM_DMA_B(0, BUF)                                                             \
-      FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) FLM_DMA_A(1, BUF) FLM_DMA_B(1, BUF)                        \
-      FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) FLM_DMA_A(2, BUF) FLM_DMA_B(2, BUF)                        \
-      FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) FLM_DMA_A(3, BUF) FLM_DMA_B(3, BUF)                        \
+      if (!(FLM_IGEMM_VAR & 8)) { FLM_DMA_A(0, BUF) FLM_DMA_B(0, BUF) }                               \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, y) if (!(FLM_IGEMM_VAR & 8)) { FLM_DMA_A(1, BUF) FLM_DMA_B(1, BUF) } \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, z) if (!(FLM_IGEMM_VAR & 8)) { FLM_DMA_A(2, BUF) FLM_DMA_B(2, BUF) } \
+      FLM_MFMA4(afy0, afy1, bfy0, bfy1, w) if (!(FLM_IGEMM_VAR & 8)) { FLM_DMA_A(3, BUF) FLM_DMA_B(3, BUF) } \
     }                                                                                                 \
     g_prev = g_cur;                                                                                   \
     g_cur = g_nx1;                                                                                    \
