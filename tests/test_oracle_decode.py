@@ -72,3 +72,16 @@ def test_live_reference_property():
             exp = ref.get_average_xy(hm, h, w, n, t)
             got = decode_ref.get_average_xy_ref(hm, n, t)
         assert float(exp[0]) == float(got[0]) and float(exp[1]) == float(got[1]), (k, h, w, n, t)
+
+
+def test_topn_gap_rel_is_the_relative_gap_at_the_nth_place():
+    """decode_ref.topn_gap_rel (the checker's "determined pair" criterion, used by bench.py and the config tests): against a
+    full sort, with ties and with n + 1 = the whole map."""
+    rng = np.random.default_rng(21)
+    m = rng.random((500, 7)).astype(np.float64)
+    m[10, 3] = m[20, 3] = m[:, 3].max() + 1.0            # a tie at the top
+    for n in (1, 4, 25, 499):
+        srt = np.sort(m, axis=0)[::-1]
+        exp = (srt[n - 1] - srt[n]) / srt[n - 1]
+        np.testing.assert_array_equal(decode_ref.topn_gap_rel(m, n), exp)
+    assert decode_ref.topn_gap_rel(m, 1)[3] == 0.0        # the tie: gap zero -> undetermined for n = 1
