@@ -1,9 +1,11 @@
 // Implicit-GEMM convolution on the matrix cores, one kernel body for two arithmetic types:
-//   fp32  v_mfma_f32_32x32x2_f32   (exact fp32: bit-for-bit an fmaf chain)         -- the parity path
+//   fp32  v_mfma_f32_32x32x2_f32   (exact fp32 products and sums)                    -- the parity path
 //   bf16  v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate, 16x the rate)  -- BASELINE configs[2]
 // Both use 128-byte operand rows (32 floats / 64 bf16) and 16-byte fragments per lane, so the tile
-// geometry, the LDS swizzle, the staging code and the fragment addressing are shared; only the MFMA
-// slot and the output conversion differ.
+// geometry, the LDS swizzle and the fragment addressing are shared; the MFMA slot and the output
+// conversion differ, and since round 3 the fp32 path has its own operand ring and summation tree
+// (template TWO: LDS-DMA staging, three accumulator sets -- chains of 32 + sqrt + sqrt roundings per
+// output instead of one fmaf chain of K; the register-staged single-chain form stays selectable for A/B).
 //
 // Covers every Conv2D of the reference's fcn_8 + vanilla_encoder except enc1
 // (networks/fcn.py:33-48 enc2..5 with ZeroPadding2D(1)+BN+ReLU+MaxPool fused; :98 fc6 7x7 'same';
@@ -27,8 +29,9 @@
 //   2  position-major (y, x, n): a tile holds one or two neighbouring spatial positions of many faces,
 //      so filter taps that fall outside the 8x8 map for the whole tile are skipped (fc6: 7x7 'same' on
 //      8x8 -- 38 % of its dense MACs multiply zero padding).  Tiles then differ in work (20..49 taps):
-//      every workgroup ranks the tiles by tap count (a few hundred integer ops) and runs the i-th
-//      heaviest and the i-th lightest back to back, so all workgroups carry about the same load.
+//      every workgroup ranks the tiles by tap count (a few hundred integer ops); the bf16 / single-chain form runs
+//      the i-th heaviest and the i-th lightest back to back, the fp32 parity form (TWO) one tile per workgroup,
+//      handed out longest-first inside each XCD's share of the grid -- either way the generations end together.
 #include "flm_igemm_args.h"
 
 // Developer variants (tools/ab_variants.py builds the file with -DFLM_IGEMM_VAR=<mask>; 0 in every shipped build):
