@@ -274,6 +274,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::tail_fused_enable(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "decode_lds_dma")) {  // standalone decode of 68-landmark maps: tiles by LDS-DMA (1) or register prefetch (0)
+    flm::decode_dma_enable(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_conv3_halo")) {  // halo-resident 3x3 kernel for 64-channel inputs: 0 off, 1 auto, 2 always
     flm::conv3_halo_enable(value);
     return FLM_OK;

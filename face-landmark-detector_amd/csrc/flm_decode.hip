@@ -269,6 +269,134 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeArgs a) {
   }
 }
 
+// ---- the same pass for 68-landmark maps with the tiles brought in by LDS-DMA (round 3) --------------------------------
+// What bounded the kernel above at batch 64 (0.31 ms, 0.49 of 8 TB/s) is bytes in flight: one 17 KiB tile of register
+// prefetch per workgroup, three workgroups per CU, 51 KiB per CU against ~3 us of loaded HBM latency.  Here a tile goes
+// from HBM to LDS by buffer_load_dwordx4 ... lds (17 requests of 1 KiB; inline assembly as in flm_igemm_args.h, so that
+// hipcc does not order the tile's ds_reads behind every pending request) into a ring of three slots: while tile t is
+// processed, tiles t+1 and t+2 are in flight -- twice the bytes, no prefetch registers.  The image of a tile is then the
+// plain [pixel][68] array (rows of 272 bytes: an odd row stride is not available to a DMA): a wave owns channels
+// 16w .. 16w+15 and 64+w and reads its pixel's values as four ds_read_b128 + one b32 -- lanes 272 bytes apart cover all
+// 32 banks once per 8 lanes, conflict-free.  The tail of a chunk is zero-filled by the buffer bounds check
+// (num_records = the chunk's bytes; the tile offset rides in the VECTOR offset, the one the check looks at).
+// One barrier per tile: a wave waits for its own requests of tile t (vmcnt), the barrier makes every wave's pieces
+// visible and proves that tile t-1 has been read by all, then tile t+2 is requested into t-1's slot.
+constexpr int DL = 68, D_TILE_B = PT * DL * 4, D_PIECES = D_TILE_B / 1024, D_RING = 3, D_PPW = (D_PIECES + 3) / 4;
+static_assert(D_TILE_B % 1024 == 0 && D_PPW == 5, "17 pieces of 1 KiB: five per wave, the missing ones repeat piece w");
+
+template <int MODE>
+__global__ __launch_bounds__(256) void decode_partial_dma_kernel(DecodeArgs a) {
+  if (a.gate && *a.gate == 0) return;
+  extern __shared__ __attribute__((aligned(16))) char ring[];  // [D_RING][PT][DL] floats
+  constexpr int CPW = 17;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int face = blockIdx.y, chunk = blockIdx.x;
+  const int HW = a.h * a.w;
+  const int p_begin = chunk * a.chunk_px;
+  const int p_end = min(p_begin + a.chunk_px, HW);
+  const int ntiles = (p_end - p_begin + PT - 1) / PT;
+  if (ntiles <= 0) return;  // (uniform)
+
+  double s0[CPW], sx[CPW], sy[CPW];                 // ALL
+  unsigned long long list[CPW], tau[CPW];           // TOPN
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    if (MODE == FLM_DECODE_ALL) {
+      s0[i] = 0.0; sx[i] = 0.0; sy[i] = 0.0;
+    } else {
+      list[i] = 0ull; tau[i] = 0ull;
+    }
+  }
+
+  typedef int dsrd_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned ring_lds = (unsigned)(size_t)((lds_char*)ring);
+  const unsigned long long cb = reinterpret_cast<unsigned long long>(a.hm + ((size_t)face * HW + p_begin) * DL);
+  const dsrd_t srd = (dsrd_t){(int)(unsigned)cb, (int)(unsigned)((cb >> 32) & 0xffffu), (p_end - p_begin) * DL * 4, 0x00020000};
+  // piece k of a tile: bytes [1024 k, 1024 k + 1024); this wave's pieces wave, wave + 4, ... (five requests per tile and
+  // wave so that the vmcnt arithmetic is the same in every wave: a piece past the 17th repeats piece `wave`)
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    const unsigned slot = ring_lds + (unsigned)(t % D_RING) * D_TILE_B;
+#pragma unroll
+    for (int j = 0; j < D_PPW; ++j) {
+      const int k = wave + 4 * j < D_PIECES ? wave + 4 * j : wave;
+      asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                   :
+                   : "v"((unsigned)t * D_TILE_B + (unsigned)k * 1024u + (unsigned)lane * 16u), "s"(srd), "{m0}"(slot + k * 1024)
+                   : "memory");
+    }
+  };
+  issue(0);
+  if (ntiles > 1) issue(1);
+  const int c16 = 16 * wave;  // this wave's channels: c16 .. c16 + 15 and 64 + wave
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) __builtin_amdgcn_s_waitcnt(0x0f75);  // vmcnt(5): tile t's five requests done, tile t+1's may fly
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (t + 2 < ntiles) issue(t + 2);
+    const char* tile = ring + (size_t)(t % D_RING) * D_TILE_B + lane * (DL * 4);
+    float v[CPW];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 q = *reinterpret_cast<const float4*>(tile + (c16 + 4 * j) * 4);
+      v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+    v[16] = *reinterpret_cast<const float*>(tile + (64 + wave) * 4);
+    const int p0 = p_begin + t * PT;
+    const int pix = p0 + lane;
+    const bool pvalid = pix < p_end;
+    if (MODE == FLM_DECODE_ALL) {
+      const double dx = (double)(pix % a.w), dy = (double)(pix / a.w);
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        const double hv = pvalid ? (double)v[i] : 0.0;
+        s0[i] += hv;
+        sx[i] = fma(hv, dx, sx[i]);
+        sy[i] = fma(hv, dy, sy[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        const unsigned long long key = pvalid ? (((unsigned long long)order_bits(v[i]) << 32) | (unsigned)pix) : 0ull;
+        if (__any(key > tau[i])) insert_candidates(list[i], tau[i], key, a.n_points, lane);
+      }
+    }
+  }
+
+  // ---- partials, in the layout of decode_partial_kernel (channel index c) --------------------------------------------
+  if (MODE == FLM_DECODE_ALL) {
+    double* part = reinterpret_cast<double*>(a.part) + ((size_t)face * a.chunks + chunk) * DL * 3;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = i < 16 ? c16 + i : 64 + wave;
+      double v0 = s0[i], v1 = sx[i], v2 = sy[i];
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) {  // fixed-order butterfly: deterministic
+        v0 += __shfl_xor(v0, sh);
+        v1 += __shfl_xor(v1, sh);
+        v2 += __shfl_xor(v2, sh);
+      }
+      if (lane == 0) {
+        part[c * 3 + 0] = v0;
+        part[c * 3 + 1] = v1;
+        part[c * 3 + 2] = v2;
+      }
+    }
+  } else {
+    unsigned long long* part =
+        reinterpret_cast<unsigned long long*>(a.part) + ((size_t)face * a.chunks + chunk) * DL * a.n_points;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = i < 16 ? c16 + i : 64 + wave;
+      if (lane < a.n_points) part[(size_t)c * a.n_points + lane] = list[i];
+    }
+  }
+}
+
+static std::atomic<int> g_decode_dma{1};  // A/B knob "decode_lds_dma": same results either way
+void decode_dma_enable(int on) { g_decode_dma.store(on, std::memory_order_relaxed); }
+
 // one wave per (face, landmark)
 template <int MODE, bool WIDE = false>
 __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a) {
@@ -620,6 +748,27 @@ int launch_decode(hipStream_t s, const float* hm, int n, int h, int w, int l, in
   const size_t lds = sizeof(float) * PT * (l | 1);
   dim3 grid(a.chunks, n);
   const bool small = l <= 68;  // 17 channels per wave
+  // 68-landmark maps, 16-byte-aligned faces, n <= 64: the LDS-DMA form (a chunk stays below the 2 GiB buffer range)
+  const bool dma = g_decode_dma.load(std::memory_order_relaxed) && l == DL && a.vec && (mode == FLM_DECODE_ALL || n_points <= 64) &&
+                   (long long)a.chunk_px * DL * 4 < (1ll << 31);
+  if (dma) {
+    constexpr size_t dlds = (size_t)D_RING * D_TILE_B;
+    if (mode == FLM_DECODE_ALL) {
+      static FuncAttrOnce attr;
+      FLM_FUNC_ATTR_ONCE(attr, (&decode_partial_dma_kernel<FLM_DECODE_ALL>), dlds);
+      decode_partial_dma_kernel<FLM_DECODE_ALL><<<grid, 256, dlds, s>>>(a);
+      FLM_LAUNCH_CHECK("decode_partial_dma_kernel");
+      decode_merge_kernel<FLM_DECODE_ALL><<<dim3(l, n), 64, 0, s>>>(a);
+    } else {
+      static FuncAttrOnce attr;
+      FLM_FUNC_ATTR_ONCE(attr, (&decode_partial_dma_kernel<FLM_DECODE_TOPN>), dlds);
+      decode_partial_dma_kernel<FLM_DECODE_TOPN><<<grid, 256, dlds, s>>>(a);
+      FLM_LAUNCH_CHECK("decode_partial_dma_kernel");
+      decode_merge_kernel<FLM_DECODE_TOPN><<<dim3(l, n), 64, 0, s>>>(a);
+    }
+    FLM_LAUNCH_CHECK("decode_merge_kernel");
+    return FLM_OK;
+  }
   if (mode == FLM_DECODE_ALL) {
     if (small) decode_partial_kernel<FLM_DECODE_ALL, 17><<<grid, 256, lds, s>>>(a);
     else decode_partial_kernel<FLM_DECODE_ALL, 24><<<grid, 256, lds, s>>>(a);

@@ -241,6 +241,9 @@ int flm_profile_filter(const char* layer);
  *   "bf16_fused_tail"       1 (default): seg_feats = crop(up4(fuse4)) + score3(f3) is ONE launch in the bf16 configuration
  *                           of the 68-class models (csrc/flm_tail_bf16.hip); 0: score3, then up4 with the skip add.
  *                           Same bits
+ *   "decode_lds_dma"        1 (default): the standalone decode of 68-landmark maps brings its tiles into a three-slot LDS
+ *                           ring by buffer_load ... lds (csrc/flm_decode.hip, decode_partial_dma_kernel); 0: one tile of
+ *                           register prefetch.  Same results
  *   "up3_cand8"             bit 0: the bf16 candidate launch of the last transposed conv runs the 8-wave kernel
  *                           (csrc/flm_convt.hip, up3_cand8_kernel); bit 2: its 4-wave x 2-workgroup shape; default 1;
  *                           0: the generic kernel.  Same keys either way.  Bit 1 (an fp32 form of that kernel) is
