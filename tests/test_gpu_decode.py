@@ -110,6 +110,28 @@ def test_wide_lists_n_up_to_128(M):
             assert np.array_equal(got, exp, equal_nan=True), (shape, n)
 
 
+def test_lds_dma_form_equals_register_prefetch_form(M):
+    """flm_set_tuning "decode_lds_dma": the LDS-DMA ring (68-landmark maps, the default) against the register-prefetch
+    kernel -- same coordinates bit for bit in top-n and all-pixel mode, on a map whose chunks end inside a tile (the
+    zero fill of the buffer bounds check) and at the headline size."""
+    from flm_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for shape in ((3, 50, 37, 68), (64, 264, 264, 68)):
+        hm = torch.rand(shape, device="cuda", generator=g)
+        hm[0, :2, :7, 3] = 0.875      # ties
+        out = {}
+        try:
+            for knob in (0, 1):
+                _lib.check(lib.flm_set_tuning(b"decode_lds_dma", knob), "set_tuning")
+                out[knob] = [M.decode_device(hm, n, 0.1).cpu().numpy() for n in (0, 1, 4, 25, 64)]
+        finally:
+            _lib.check(lib.flm_set_tuning(b"decode_lds_dma", 1), "set_tuning")
+        for a, b, n in zip(out[0], out[1], (0, 1, 4, 25, 64)):
+            assert np.array_equal(a, b, equal_nan=True), (shape, n)
+        del hm
+
+
 def test_unsupported_n_points_raises(M):
     from flm_amd._lib import FlmError
     with pytest.raises(FlmError):
