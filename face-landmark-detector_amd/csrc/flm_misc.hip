@@ -2,6 +2,8 @@
 // alignment warp, crop front-end.
 #include "flm_common.h"
 
+#include <atomic>
+
 namespace flm {
 
 // ---- get_image_array (reference data/generator.py:29-69) for crops already at model size ------------
@@ -115,6 +117,16 @@ int launch_similarity(hipStream_t s, const double* lm, const double* tmpl, int n
 //   clamp xs to [0, Ws-1], ys to [0, Hs-1]   (skimage warp mode="edge", data/generator.py:200)
 //   x0 = floor(xs), fx = xs-x0, x1 = min(x0+1, Ws-1)  (same for y)
 //   top = fma(fx, p01-p00, p00); bot = fma(fx, p11-p10, p10); out = fma(fy, bot-top, top)
+// The aligned faces are written once and read by a later launch (or by the host): their stores carry the non-temporal
+// hint, so that the 786,432 B a face writes stream past the L2 instead of evicting the source lines the gathers of
+// the neighbouring pixels are about to re-read (batch 512: 0.161 -> 0.104 ms; the PMC's FETCH_SIZE had shown the
+// source fetched twice).
+__device__ __forceinline__ void store_stream16(float* p, const float4& v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v vv = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(p));
+}
+
 template <bool U8>
 __global__ __launch_bounds__(256) void warp_kernel(const void* __restrict__ src, int hs, int ws,
                                                    const float* __restrict__ m, float* __restrict__ dst, int hd,
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const void* __restrict__ src,
       __builtin_amdgcn_wave_barrier();
       if (lane < 48) {
         const float4 v = *reinterpret_cast<const float4*>(&stage[wv][4 * lane]);
-        *reinterpret_cast<float4*>(dface + pbase * 3 + 4 * lane) = v;
+        store_stream16(dface + pbase * 3 + 4 * lane, v);
       }
       __builtin_amdgcn_wave_barrier();
     } else if (live) {
@@ -216,6 +228,11 @@ __global__ __launch_bounds__(256) void warp_kernel(const void* __restrict__ src,
 // with one pixel at a time the waves spent 72 % of their cycles parked on the four dword loads of a pixel (PMC), and
 // a CU's 32 waves x 4 loads x 256 B in flight bound the kernel by latency, not by bytes.  Same arithmetic per pixel as
 // warp_kernel<true>, operation for operation.
+// Developer timing ablations (tools/ab_variants.py, -DFLM_WARP_VAR=<mask>; results wrong; 0 in shipped builds):
+// 1 no output stores, 2 every gather reads the face's first bytes (perfect locality), 4 no gathers at all.
+#ifndef FLM_WARP_VAR
+#define FLM_WARP_VAR 0
+#endif
 template <int UNR>
 __global__ __launch_bounds__(256) void warp_u8_kernel(const uint8_t* __restrict__ src, int hs, int ws,
                                                       const float* __restrict__ m, float* __restrict__ dst, int hd,
@@ -256,11 +273,16 @@ __global__ __launch_bounds__(256) void warp_u8_kernel(const uint8_t* __restrict_
       const int y1 = min(y0 + 1, hs - 1);
       const int xl = min(x0, ws - 2);  // the pair (xl, xl + 1): see warp_kernel
       second[k] = x0 != xl;
-      const int ot = (y0 * ws + xl) * 3, ob = (y1 * ws + xl) * 3;
+      int ot = (y0 * ws + xl) * 3, ob = (y1 * ws + xl) * 3;
+      if (FLM_WARP_VAR & 2) { ot = (ot & 3) + 4 * lane; ob = (ob & 3) + 4 * lane + 512; }
+      if (FLM_WARP_VAR & 4) {
+        ta[k] = (unsigned)ot; tb[k] = (unsigned)ob; ba[k] = (unsigned)(ot + ob); bb[k] = (unsigned)(ot ^ ob);
+      } else {
       __builtin_memcpy(&ta[k], s8 + ot, 4);
       __builtin_memcpy(&tb[k], s8 + ot + 2, 4);
       __builtin_memcpy(&ba[k], s8 + ob, 4);
       __builtin_memcpy(&bb[k], s8 + ob + 2, 4);
+      }
     }
 #pragma unroll
     for (int k = 0; k < UNR; ++k) {
@@ -287,7 +309,7 @@ __global__ __launch_bounds__(256) void warp_u8_kernel(const uint8_t* __restrict_
         __builtin_amdgcn_wave_barrier();
         if (lane < 48) {
           const float4 v = *reinterpret_cast<const float4*>(&stage[wv][4 * lane]);
-          *reinterpret_cast<float4*>(dface + pbase * 3 + 4 * lane) = v;
+          if (!(FLM_WARP_VAR & 1) || v.x == 12345.678f) store_stream16(dface + pbase * 3 + 4 * lane, v);
         }
         __builtin_amdgcn_wave_barrier();
       } else if (p < npix) {
@@ -298,12 +320,114 @@ __global__ __launch_bounds__(256) void warp_u8_kernel(const uint8_t* __restrict_
   }
 }
 
+static std::atomic<int> g_warp_rows{1};  // A/B knob "warp_rows": same results either way
+void warp_rows_enable(int on) { g_warp_rows.store(on, std::memory_order_relaxed); }
+
+// uint8 sources, destination width a multiple of 64: one wave = 64 consecutive pixels of ONE output row, a workgroup
+// = a 64 x (4 * ROWS) patch of the destination (grid: x segments, row groups, faces).  What the FLM_WARP_VAR ablations
+// of warp_u8_kernel showed at batch 512 (0.163 ms as shipped): 0.092 ms without the stores, 0.090 ms without the
+// gathers, 0.080 ms with neither -- (a) gathers and stores each cost little alone and nearly their sum together: the
+// written faces were displacing the source from the L2 (store_stream16 above: 0.163 -> 0.109 ms), and (b) the floor
+// is the kernel's own VALU work, about 150 instructions per pixel with the quarter-rate 32-bit integer multiplies of
+// the pixel -> (row, column) division and of the byte offsets.  Here
+//   - the row and the segment come from the block and wave indices: no division, the row terms are one per wave,
+//   - the byte offsets use 24-bit multiplies (full rate; the launcher checks hs, ws < 2^24),
+//   - the x0 = ws - 1 case is expressed through the weight instead of six selects: the pair starts at xl = ws - 2 and
+//     fx becomes 1, fmaf(1, t1 - t0, t0) = t1 exactly (small integers), the value warp_kernel computes,
+// and the patch keeps a workgroup's gathers inside a few source rows.  Per pixel the arithmetic is warp_kernel<true>'s,
+// the results the same bits (tests/test_gpu_align.py).  Batch 512: 0.109 -> 0.094 ms (0.66 of 8 TB/s by the algorithmic
+// 983,040 B per face), batch 64: 0.0164 -> 0.0140 ms (0.56); random rotations up to 0.6 rad with scales 0.6-1.8: the same
+// time as the pixel-list kernel.
+template <int ROWS>
+__global__ __launch_bounds__(256) void warp_u8_rows_kernel(const uint8_t* __restrict__ src, int hs, int ws,
+                                                           const float* __restrict__ m, float* __restrict__ dst,
+                                                           int hd, int wd) {
+  const int f = blockIdx.z;
+  const float* mm = m + (size_t)f * 6;
+  const float m00 = mm[0], m01 = mm[1], m02 = mm[2], m10 = mm[3], m11 = mm[4], m12 = mm[5];
+  const float det = fmaf(m00, m11, -(m01 * m10));
+  const float idet = 1.0f / det;
+  const float i00 = m11 * idet, i01 = -m01 * idet, i10 = -m10 * idet, i11 = m00 * idet;
+  const float i02 = -fmaf(i00, m02, i01 * m12), i12 = -fmaf(i10, m02, i11 * m12);
+  const uint8_t* s8 = src + (size_t)f * hs * ws * 3;
+  float* dface = dst + (size_t)f * hd * wd * 3;
+  __shared__ float stage[4][192];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xseg = blockIdx.x * 64;
+  const int row0 = (blockIdx.y * 4 + wv) * ROWS;
+  const float xd = (float)(xseg + lane);
+  const float xmax = (float)(ws - 1), ymax = (float)(hs - 1);
+  const unsigned ws3 = (unsigned)ws * 3u;
+  float fx[ROWS], fy[ROWS];
+  unsigned ta[ROWS], tb[ROWS], ba[ROWS], bb[ROWS];
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const int row = min(row0 + k, hd - 1);  // rows past the image repeat the last one (loaded, never stored)
+    const float yd = (float)row;
+    float xs = fmaf(i00, xd, fmaf(i01, yd, i02));
+    float ys = fmaf(i10, xd, fmaf(i11, yd, i12));
+    xs = fminf(fmaxf(xs, 0.f), xmax);
+    ys = fminf(fmaxf(ys, 0.f), ymax);
+    const float xf = floorf(xs), yf = floorf(ys);
+    fy[k] = ys - yf;
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int xl = min(x0, ws - 2);
+    fx[k] = x0 != xl ? 1.0f : xs - xf;
+    const unsigned ot = (__umul24((unsigned)y0, (unsigned)ws) + (unsigned)xl) * 3u;
+    const unsigned ob = ot + (y0 + 1 < hs ? ws3 : 0u);
+    if (FLM_WARP_VAR & 4) {
+      ta[k] = ot; tb[k] = ob; ba[k] = ot + ob; bb[k] = ot ^ ob;
+    } else {
+    __builtin_memcpy(&ta[k], s8 + ot, 4);
+    __builtin_memcpy(&tb[k], s8 + ot + 2, 4);
+    __builtin_memcpy(&ba[k], s8 + ob, 4);
+    __builtin_memcpy(&bb[k], s8 + ob + 2, 4);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const int row = row0 + k;
+    if (row >= hd) break;  // (wave-uniform)
+    const float t0[3] = {(float)(ta[k] & 0xffu), (float)((ta[k] >> 8) & 0xffu), (float)((ta[k] >> 16) & 0xffu)};
+    const float t1[3] = {(float)(ta[k] >> 24), (float)((tb[k] >> 16) & 0xffu), (float)(tb[k] >> 24)};
+    const float b0[3] = {(float)(ba[k] & 0xffu), (float)((ba[k] >> 8) & 0xffu), (float)((ba[k] >> 16) & 0xffu)};
+    const float b1[3] = {(float)(ba[k] >> 24), (float)((bb[k] >> 16) & 0xffu), (float)(bb[k] >> 24)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float top = fmaf(fx[k], t1[c] - t0[c], t0[c]);
+      const float bot = fmaf(fx[k], b1[c] - b0[c], b0[c]);
+      stage[wv][3 * lane + c] = fmaf(fy[k], bot - top, top);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 48) {
+      const float4 v = *reinterpret_cast<const float4*>(&stage[wv][4 * lane]);
+      if (!(FLM_WARP_VAR & 1) || v.x == 12345.678f) store_stream16(dface + ((size_t)row * wd + xseg) * 3 + 4 * lane, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, int ws, const float* m, float* dst,
                 int hd, int wd) {
   if (n <= 0 || hs <= 0 || ws <= 0 || hd <= 0 || wd <= 0 || n > 65535 || (long long)hs * ws * 12 >= (1ll << 31) ||
       (long long)hd * wd * 12 >= (1ll << 31)) {
     set_error("warp: bad sizes (a face must stay below 2^31 bytes on either side)");
     return FLM_ERR_SHAPE;
+  }
+  if (src_is_u8 && ws >= 2 && (wd & 63) == 0 && hs < (1 << 24) && ws < (1 << 24) &&
+      g_warp_rows.load(std::memory_order_relaxed)) {
+    const int rows_knob = g_warp_rows.load(std::memory_order_relaxed);
+    const int rows = rows_knob == 1 ? 4 : rows_knob;
+    const int gy = cdiv(hd, 4 * rows);
+    if (gy <= 65535) {
+      const dim3 grid(wd / 64, gy, n);
+      const uint8_t* s8 = static_cast<const uint8_t*>(src);
+      if (rows == 2) warp_u8_rows_kernel<2><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
+      else if (rows == 8) warp_u8_rows_kernel<8><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
+      else warp_u8_rows_kernel<4><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
+      FLM_LAUNCH_CHECK("warp_u8_rows_kernel");
+      return FLM_OK;
+    }
   }
   if (src_is_u8 && ws >= 2) {
     constexpr int UNR = 4;  // (2: 0.165 ms, 4: 0.161-0.163, 8: 0.164, 16: 0.192 per 512 faces)
