@@ -393,7 +393,7 @@ def hbm_kernels(lib, dev, only=None):
         hm = torch.rand((nb, 264, 264, 68), dtype=torch.float32, device=dev)
         ms = timeit(lambda: decode_device(hm, 4, 0.0))
         gbs = DECODE_BYTES_PER_FACE * nb / ms / 1e6
-        out["decode_top4_b%d" % nb] = {"bound": "hbm", "kernel": "decode_partial_kernel + decode_merge_kernel (flm_decode, "
+        out["decode_top4_b%d" % nb] = {"bound": "hbm", "kernel": "decode_partial_dma_kernel + decode_merge_kernel (flm_decode, "
                                        "float32 [%d,264,264,68] -> landmarks)" % nb, "achieved": gbs, "peak": PEAK_HBM_GBS,
                                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": ms,
                                        "bytes_per_launch": DECODE_BYTES_PER_FACE * nb,
@@ -407,7 +407,7 @@ def hbm_kernels(lib, dev, only=None):
         dst = torch.empty((nb, 256, 256, 3), dtype=torch.float32, device=dev)
         ms = timeit(lambda: alignment.warp_device(src, m, 256, 256, out=dst))
         gbs = WARP_BYTES_PER_FACE * nb / ms / 1e6
-        out["warp_b%d" % nb] = {"bound": "hbm", "kernel": "warp_kernel (flm_warp_affine, u8 [%d,256,256,3] -> f32)" % nb,
+        out["warp_b%d" % nb] = {"bound": "hbm", "kernel": "warp_u8_rows_kernel (flm_warp_affine, u8 [%d,256,256,3] -> f32)" % nb,
                                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                 "avg_launch_ms": ms, "bytes_per_launch": WARP_BYTES_PER_FACE * nb,
                                 "traffic": load_traffic("traffic_latest.json", "warp_b%d" % nb)}

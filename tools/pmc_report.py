@@ -49,7 +49,7 @@ def layer_f32(name, grid):
         return "decode"
     if "cand_tau" in name:
         return "tau"
-    if "warp_kernel" in name or "warp_u8_kernel" in name:
+    if "flm::warp_" in name:
         return "warp"
     if "similarity" in name:
         return "similarity"
@@ -92,7 +92,7 @@ def layer_bf16(name, grid):
         return "decode"
     if "cand_tau" in name:
         return "tau"
-    if "warp_kernel" in name or "warp_u8_kernel" in name:
+    if "flm::warp_" in name:
         return "warp"
     return None
 
@@ -103,8 +103,8 @@ def layer_hbm(name, grid):
         # of this table mix the two, so no traffic entry is derived for the standalone decode (round 1 measured it on
         # its own: 1.218 GB per batch-64 launch against 1.213 GB algorithmic)
         return None
-    if "warp_kernel" in name or "warp_u8_kernel" in name:
-        # warp_u8_kernel<4> runs a thread per 4 output pixels: 64 faces = 1,048,576 threads
+    if "flm::warp_" in name:
+        # warp_u8_rows_kernel<4> (and warp_u8_kernel<4>) run a thread per 4 output pixels: 64 faces = 1,048,576 threads
         return "warp_b64" if grid <= 64 * 256 * 256 // 4 else "warp_b512"
     return None
 
