@@ -143,10 +143,14 @@ def timed_region(step, steps, warmup, world=1, device=None, settle_s=0.0, before
     on_gpu = device is not None and getattr(device, "type", "cpu") == "cuda"
 
     def fence():
+        # a pipelined step (pipeline_gather at N > 1) leaves its last all-gather in flight: it belongs to the region
+        # that is closing; returns that gather's result (None otherwise)
+        last = step.drain() if hasattr(step, "drain") else None
         if world > 1:
             dist.barrier()
         if on_gpu:
             torch.cuda.synchronize()
+        return last
 
     out = None
     for _ in range(warmup):
@@ -173,8 +177,10 @@ def timed_region(step, steps, warmup, world=1, device=None, settle_s=0.0, before
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
-    fence()
+    last = fence()
     dt = time.perf_counter() - t0
+    if last is not None:
+        out = (last,) + tuple(out[1:])   # the last step's own gather
     mine = [1e3 * dt / max(steps, 1)]
     if world > 1:
         every = torch.zeros(world, dtype=torch.float64, device=device if on_gpu else "cpu")
@@ -237,6 +243,32 @@ def describe_collective(world, device=None, payload_rows=0, classes=68, dtype_na
                                  "exchange is latency-bound either way"}
 
 
+def pipeline_gather(produce, world, total):
+    """step() for N ranks: `produce()` queues this rank's batch and returns (landmarks [b, C, 2], aux); its all-gather is
+    queued behind it (RCCL's own stream) and the PREVIOUS step's gather is waited for only then -- the exchange of batch
+    i hides behind the kernels of batch i + 1 instead of stalling the stream once per batch.  step() returns (the
+    previous step's gathered landmarks or None, aux); step.drain() waits for the one still in flight (timed_region calls
+    it before closing a region, so K timed steps contain K complete exchanges).  N = 1: no exchange, (landmarks, aux)."""
+    from flm_amd import distributed
+    pending = [None]
+
+    def step():
+        lm, aux = produce()
+        if world <= 1:
+            return lm, aux
+        nxt = distributed.all_gather_landmarks_async(lm, total)
+        full = pending[0].wait() if pending[0] is not None else None
+        pending[0] = nxt
+        return full, aux
+
+    def drain():
+        full = pending[0].wait() if pending[0] is not None else None
+        pending[0] = None
+        return full
+    step.drain = drain
+    return step
+
+
 class Workload:
     """One configuration of the step on this rank: model, resident crops, template."""
 
@@ -257,16 +289,15 @@ class Workload:
         self.scale = (self.W / self.model.output_width, self.H / self.model.output_height)
 
     def make_step(self, world, total):
-        from flm_amd import alignment, distributed
+        from flm_amd import alignment
 
-        def step():
+        def produce():
             lm = self.model.forward_device(self.crops, "landmarks", n_points=self.n_points, thresh=0.0)
             aligned = None
             if self.align:
                 aligned, _m = alignment.align_device(self.crops, lm, self.tmpl, self.H, self.W, self.scale)
-            full = distributed.all_gather_landmarks(lm, total) if world > 1 else lm
-            return full, aligned
-        return step
+            return lm, aligned
+        return pipeline_gather(produce, world, total)
 
 
 class StreamWorkload:
@@ -329,6 +360,8 @@ def measure(lib, wl, steps, warmup, world, roof_layer, settle_s):
     lib.flm_profile_reset()
     for _ in range(LAYER_PASS_STEPS):
         step()
+    if hasattr(step, "drain"):
+        step.drain()
     torch.cuda.synchronize()
     layers = read_profile(lib)
     lib.flm_profile_disable()

@@ -335,9 +335,9 @@ void warp_rows_enable(int on) { g_warp_rows.store(on, std::memory_order_relaxed)
 //   - the x0 = ws - 1 case is expressed through the weight instead of six selects: the pair starts at xl = ws - 2 and
 //     fx becomes 1, fmaf(1, t1 - t0, t0) = t1 exactly (small integers), the value warp_kernel computes,
 // and the patch keeps a workgroup's gathers inside a few source rows.  Per pixel the arithmetic is warp_kernel<true>'s,
-// the results the same bits (tests/test_gpu_align.py).  Batch 512: 0.109 -> 0.094 ms (0.66 of 8 TB/s by the algorithmic
+// the results the same bits (tests/test_gpu_align.py).  Batch 512: 0.109 -> 0.095 ms (0.66 of 8 TB/s by the algorithmic
 // 983,040 B per face), batch 64: 0.0164 -> 0.0140 ms (0.56); random rotations up to 0.6 rad with scales 0.6-1.8: the same
-// time as the pixel-list kernel.
+// time as the pixel-list kernel or better.
 template <int ROWS>
 __global__ __launch_bounds__(256) void warp_u8_rows_kernel(const uint8_t* __restrict__ src, int hs, int ws,
                                                            const float* __restrict__ m, float* __restrict__ dst,
@@ -417,14 +417,17 @@ int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, in
   if (src_is_u8 && ws >= 2 && (wd & 63) == 0 && hs < (1 << 24) && ws < (1 << 24) &&
       g_warp_rows.load(std::memory_order_relaxed)) {
     const int rows_knob = g_warp_rows.load(std::memory_order_relaxed);
-    const int rows = rows_knob == 1 ? 4 : rows_knob;
+    // rows per wave: 2 by default.  Near-identity transforms run the same with 2, 4 or 8 (batch 512: 0.095 ms); the
+    // degenerate ones the bench pipeline produces (landmarks of random weights: scale ~0.07, nearly every sample clamps
+    // to the source's border) cost 0.117 / 0.128 / 0.168 ms with 2 / 4 / 8 (pixel-list kernel: 0.114)
+    const int rows = rows_knob == 1 ? 2 : rows_knob;
     const int gy = cdiv(hd, 4 * rows);
     if (gy <= 65535) {
       const dim3 grid(wd / 64, gy, n);
       const uint8_t* s8 = static_cast<const uint8_t*>(src);
-      if (rows == 2) warp_u8_rows_kernel<2><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
+      if (rows == 4) warp_u8_rows_kernel<4><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
       else if (rows == 8) warp_u8_rows_kernel<8><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
-      else warp_u8_rows_kernel<4><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
+      else warp_u8_rows_kernel<2><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
       FLM_LAUNCH_CHECK("warp_u8_rows_kernel");
       return FLM_OK;
     }

@@ -80,6 +80,62 @@ def all_gather_landmarks(local, total: int, group=None):
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], 0)
 
 
+class PendingGather:
+    """A landmark all-gather in flight (`all_gather_landmarks_async`): `wait()` returns the full [total, C, 2] tensor.
+    With RCCL the wait is a stream dependency, not a host block: kernels launched on the current stream BEFORE the call
+    are not held up by the collective."""
+
+    def __init__(self, work, out, counts, mx, device):
+        self._work, self._out, self._counts, self._mx, self._device = work, out, counts, mx, device
+
+    def wait(self):
+        import torch
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out = self._out
+        if self._device is not None:          # gloo dry run with CUDA shards: the gather ran on host tensors
+            out = out.to(self._device)
+        if all(c == self._mx for c in self._counts):
+            return out
+        return torch.cat([out[r * self._mx:r * self._mx + c] for r, c in enumerate(self._counts)], 0)
+
+
+def all_gather_landmarks_async(local, total: int, group=None, single_rank_collective=False):
+    """`all_gather_landmarks` without waiting for it: the collective is queued behind the work already on the current
+    stream (RCCL runs it on its own stream) and a `PendingGather` comes back.  The shard is COPIED first, so the caller
+    may overwrite `local` (the next batch's decode) while the exchange is in flight.  A pipeline waits for the gather of
+    batch i after it has launched batch i + 1 (bench.py): the exchange then hides behind that batch's kernels instead
+    of stalling the stream for its latency once per batch."""
+    import torch
+    import torch.distributed as dist
+    alone = not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1
+    if alone and not (single_rank_collective and dist.is_available() and dist.is_initialized()):
+        # (single_rank_collective: run the exchange even with one rank -- tests/test_gpu_rccl.py drives the RCCL call
+        #  sequence of the pipelined step on a one-GPU box that way)
+        if local.shape[0] != total:
+            raise ValueError("single process: shard has %d rows, expected %d" % (local.shape[0], total))
+        return PendingGather(None, local, [total], total, None)
+    world = dist.get_world_size(group)
+    counts = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
+    mx = max(counts)
+    rank = dist.get_rank(group)
+    if local.shape[0] != counts[rank]:
+        raise ValueError("rank %d holds %d rows, its shard has %d" % (rank, local.shape[0], counts[rank]))
+    tail = tuple(local.shape[1:])
+    if mx != local.shape[0]:
+        send = torch.cat([local, torch.zeros((mx - local.shape[0],) + tail, dtype=local.dtype, device=local.device)], 0)
+    else:
+        send = local.clone()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty((world * mx,) + tail, dtype=local.dtype)
+        work = dist.all_gather_into_tensor(host, send.cpu(), group=group, async_op=True)
+        return PendingGather(work, host, counts, mx, local.device)
+    out = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
+    return PendingGather(work, out, counts, mx, None)
+
+
 def sharded_predict(predict_fn, batch, total: int, group=None):
     """Run `predict_fn(local_batch) -> [b_r, C, 2]` on this rank's slice and gather.
     `batch` is this rank's slice (already resident on its device)."""

@@ -37,20 +37,27 @@ def _worker(rank, world, port, out_dir, total):
     per_rank = hi - lo
     calls = []
 
-    def step():   # injected predict: rank r's landmarks are r + face/10000, then the real gather
+    buf = torch.empty((per_rank, 68, 2), dtype=torch.float64)   # ONE output buffer, overwritten by every step
+
+    def produce():   # injected predict: rank r's landmarks are r + face/10000 + step/100
         calls.append(1)
         if rank == world - 1:
             time.sleep(0.02)   # the slower rank sets the job's time
-        lm = torch.arange(per_rank, dtype=torch.float64).reshape(per_rank, 1, 1).expand(per_rank, 68, 2) / 10000 + rank
-        return distributed.all_gather_landmarks(lm.contiguous(), total), None
+        buf.copy_(torch.arange(per_rank, dtype=torch.float64).reshape(per_rank, 1, 1).expand(per_rank, 68, 2) / 10000
+                  + rank + len(calls) / 100)
+        return buf, None
+
+    # the bench's own step: the gather of step i is waited for after step i + 1 has been queued, the last one by the
+    # closing fence of the timed region
+    step = bench.pipeline_gather(produce, world, total)
 
     dt, (full, _), stats = bench.timed_region(step, steps=4, warmup=2, world=world, device=torch.device("cpu"))
     coll = bench.describe_collective(world, torch.device("cpu"), per_rank, 68)
     gather_ms = bench.time_gather(world, torch.device("cpu"), 512 if total % world == 0 else 8, 68, reps=3)
     starts = [distributed.shard_range(total, r, world)[0] for r in range(world)]
     rec = {"dt": dt, "calls": len(calls), "coll": coll, "rows": int(full.shape[0]), "per_rank": per_rank, "stats": stats,
-           "gather_ms": gather_ms, "first_of_each_rank": [float(full[st, 0, 0]) for st in starts],
-           "last_row": float(full[total - 1, 5, 1])}
+           "gather_ms": gather_ms, "first_of_each_rank": [round(float(full[st, 0, 0]) - 0.06, 6) for st in starts],
+           "last_row": float(full[total - 1, 5, 1]) - 0.06}   # 0.06: the result is the LAST (sixth) call's gather
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
         json.dump(rec, f)
     dist.barrier()

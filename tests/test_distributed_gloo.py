@@ -2,7 +2,7 @@
 
 The per-rank compute is injected (the oracle's decode on CPU, standing in for the HIP path,
 which needs a GPU); what is under test is `distributed.shard_range`, `all_gather_landmarks`
-(equal and ragged shards) and `sharded_predict`.
+(equal and ragged shards), its pipelined form `all_gather_landmarks_async`, and `sharded_predict`.
 """
 import os
 import socket
@@ -42,6 +42,12 @@ def _worker(rank, world, port, total, out_dir):
 
     full = distributed.sharded_predict(predict_fn, hm_all[lo:hi], total)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
+    # the same exchange without waiting for it: the shard may be overwritten while the gather is in flight
+    mine = predict_fn(hm_all[lo:hi])
+    pend = distributed.all_gather_landmarks_async(mine, total)
+    mine.fill_(-7.0)
+    assert torch.equal(pend.wait(), full)
+    assert torch.equal(pend.wait(), full)     # waiting twice is harmless
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
@@ -69,3 +75,6 @@ def test_single_process_gather_is_identity():
     assert distributed.all_gather_landmarks(x, 4) is x
     with pytest.raises(ValueError):
         distributed.all_gather_landmarks(x, 5)
+    assert distributed.all_gather_landmarks_async(x, 4).wait() is x
+    with pytest.raises(ValueError):
+        distributed.all_gather_landmarks_async(x, 5)

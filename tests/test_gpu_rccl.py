@@ -2,8 +2,8 @@
 
 A one-GPU box cannot run two RCCL ranks (RCCL refuses two ranks on one device), so what this pins is narrower than
 the world-2 gloo tests: that `backend="nccl"` initialises on this image with the environment `distributed.py` sets
-(dmabuf IPC), and that `all_gather_into_tensor` / `all_reduce(MIN)` / `barrier` -- the three calls of bench.py's
-multi-rank flow -- run on device tensors produced by the HIP path.  The N > 1 numbers are the driver's to measure.
+(dmabuf IPC), and that `all_gather_into_tensor` (blocking, and queued / waited for later as bench.py's pipelined step does) /
+`all_reduce(MIN)` / `barrier` -- the calls of bench.py's multi-rank flow -- run on device tensors produced by the HIP path.  The N > 1 numbers are the driver's to measure.
 """
 import os
 import subprocess
@@ -29,6 +29,22 @@ lm = decode_device(hm, n_points=4, thresh=0.0)                    # [4, 6, 2] on
 out = torch.empty_like(lm)
 dist.all_gather_into_tensor(out, lm.contiguous())
 assert torch.equal(out, lm)
+# the pipelined step of bench.py (pipeline_gather): the gather of batch i is queued behind it on RCCL's stream and
+# waited for after batch i + 1 has been queued; the decode writes the SAME output buffer every batch
+from flm_amd import distributed
+buf = torch.empty_like(lm)
+pending, got, want = None, [], []
+for i in range(4):
+    hm_i = hm * (1.0 + 0.25 * i) + 0.01 * i
+    decode_device(hm_i, n_points=4, thresh=0.0, out=buf)
+    want.append(decode_device(hm_i, n_points=4, thresh=0.0).clone())
+    nxt = distributed.all_gather_landmarks_async(buf, 4, single_rank_collective=True)
+    if pending is not None:
+        got.append(pending.wait())
+    pending = nxt
+got.append(pending.wait())
+torch.cuda.synchronize()
+assert len(got) == 4 and all(torch.equal(g, w) for g, w in zip(got, want)), "pipelined gathers"
 n = torch.tensor([7], device="cuda", dtype=torch.int64)
 dist.all_reduce(n, op=dist.ReduceOp.MIN)
 assert int(n.item()) == 7
