@@ -278,6 +278,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::decode_dma_enable(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "posmajor_order")) {  // fc6 at batches below a tile's rows: positions sharing a tile chosen by their taps (1) or in map order (0)
+    flm::igemm_posperm_enable(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "warp_rows")) {  // uint8 warp, destination width % 64 == 0: a wave per row segment (1; 4 / 8: that many
                                     // rows per wave instead of 2) or the pixel-list kernel (0)
     if (value != 0 && value != 1 && value != 4 && value != 8) {

@@ -181,6 +181,7 @@ void score1x1_enable(int on);
 void tail_fused_enable(int on);
 void decode_dma_enable(int on);
 void warp_rows_enable(int on);
+void igemm_posperm_enable(int on);
 // seg_feats = crop(up4(fuse4)) + score3(f3) in one launch (flm_tail_bf16.hip; bf16, 68 classes, 256-channel f3):
 // 1 launched, 0 shape left to the two-launch form, < 0 error
 int launch_seg_fused_bf16(hipStream_t s, const float* fuse4, const void* w4_packed, const void* f3, const void* w3,

@@ -32,6 +32,8 @@
 //      every workgroup ranks the tiles by tap count (a few hundred integer ops); the bf16 / single-chain form runs
 //      the i-th heaviest and the i-th lightest back to back, the fp32 parity form (TWO) one tile per workgroup,
 //      handed out longest-first inside each XCD's share of the grid -- either way the generations end together.
+#include <vector>
+
 #include "flm_igemm_args.h"
 
 // Developer variants (tools/ab_variants.py builds the file with -DFLM_IGEMM_VAR=<mask>; 0 in every shipped build):
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     for (int idx = tid; idx < a.mtiles * npp; idx += 256) {
       const int t = idx / npp, m_lo = t * BM, m_hi = (m_lo + BM < a.M ? m_lo + BM : a.M) - 1;
       const int p = m_lo / a.n + (idx - t * npp);
-      if (p <= m_hi / a.n) atomicOr(&tmask[t], posmajor_posmask(p, a.h, a.w, a.kh, a.kw, a.pad));
+      if (p <= m_hi / a.n) atomicOr(&tmask[t], posmajor_posmask(posmajor_pos(a, p), a.h, a.w, a.kh, a.kw, a.pad));
     }
     __syncthreads();
     for (int t = tid; t < a.mtiles; t += 256) wk[t] = __builtin_popcountll(tmask[t]);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       pn[j] = q / (wp * hp);
     } else {
       pn[j] = mm % a.n;
-      const int pos = mm / a.n;
+      const int pos = posmajor_pos(a, mm / a.n);
       py[j] = pos / a.w;
       px[j] = pos % a.w;
     }
@@ -643,20 +645,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         }
       } else {
         const int m_first = mbase + 4 * lh;
-        const int nn0 = MMAP == 2 ? m_first % a.n : 0, pos0 = MMAP == 2 ? m_first / a.n : 0;
+        const int nn0 = MMAP == 2 ? m_first % a.n : 0;
+        const int pos0 = MMAP == 2 ? posmajor_pos(a, m_first / a.n) : 0, pos1 = MMAP == 2 ? posmajor_pos(a, m_first / a.n + 1) : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float u = fmaf(acc[i][j][r], sc, sh);
           if (a.ksplit > 1) {  // raw partial sums, stored in output row order
             if (cok && m < a.M) {
-              const size_t prow = (MMAP == 2) ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
+              const size_t prow = (MMAP == 2) ? posmajor_orow(m, m_first, nn0, pos0, pos1, a.n, a.h * a.w) : (size_t)m;
               a.part[((size_t)blockIdx.y * a.M + prow) * a.ldc + col] = acc[i][j][r];
             }
             continue;
           }
           if (cok && m < a.M) {
-            const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, a.n, a.h * a.w) : (size_t)m;
+            const size_t orow = MMAP == 2 ? posmajor_orow(m, m_first, nn0, pos0, pos1, a.n, a.h * a.w) : (size_t)m;
             const size_t o = orow * a.ldc + col;
             if (MMAP == 0 && a.res) {  // residual add before the activation (ResNet bottlenecks)
               if (BF) u += (float)__builtin_bit_cast(__bf16, reinterpret_cast<const unsigned short*>(a.res)[o]);
@@ -673,8 +676,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   }  // pass
 }
 
+static std::atomic<int> g_posperm{1};  // A/B knob "posmajor_order": same results either way
+void igemm_posperm_enable(int on) { g_posperm.store(on, std::memory_order_relaxed); }
+int igemm_posperm_enabled() { return g_posperm.load(std::memory_order_relaxed); }
+static std::mutex g_posperm_mu;
+static std::vector<PospermEntry> g_posperm_cache;
+static bool posperm_same(const PospermEntry& x, const PospermEntry& y) {
+  return x.h == y.h && x.w == y.w && x.kh == y.kh && x.kw == y.kw && x.pad == y.pad && x.g == y.g;
+}
+bool posperm_cache_get(PospermEntry& e) {
+  std::lock_guard<std::mutex> lock(g_posperm_mu);
+  for (const PospermEntry& c : g_posperm_cache)
+    if (posperm_same(c, e)) { e = c; return true; }
+  return false;
+}
+void posperm_cache_put(const PospermEntry& e) {
+  std::lock_guard<std::mutex> lock(g_posperm_mu);
+  for (const PospermEntry& c : g_posperm_cache)
+    if (posperm_same(c, e)) return;
+  if (g_posperm_cache.size() < 64) g_posperm_cache.push_back(e);
+}
+
 template <bool BF, int MMAP, bool RELU, bool TWO = false>
-static int launch_t(hipStream_t s, const IgemmArgs& a) {
+static int launch_t(hipStream_t s, const IgemmArgs& a_in) {
+  IgemmArgs a = a_in;
+  if (MMAP == 2) posmajor_fill_perm(a, BM);
   const size_t lds = sizeof(float) * 4 * TILE_F + 64;
   static FuncAttrOnce attr;
   FLM_FUNC_ATTR_ONCE(attr, (&igemm_kernel<BF, MMAP, RELU, TWO>), lds);
@@ -794,6 +820,8 @@ int launch_igemm(hipStream_t s, const IgemmDesc& d) {
   a.ksplit = 1;
   a.gm = a.gn = 1;
   a.grp_magic = 0;
+  a.posperm_on = 0;
+  for (int k = 0; k < 8; ++k) a.posperm[k] = 0ull;
   a.part = nullptr;
   const int tiles = cdiv(a.M, BM) * cdiv(d.cout, BN);
   // The slice count is a step function of the tile count, the same for fc6 and fc7 (<= 64 tiles, i.e. up to 4

@@ -27,7 +27,22 @@ struct IgemmArgs {
   float* part;  // [ksplit][M][ldc]
   int grp_magic;  // fp32 three-level accumulation: ceil(65536 / steps per group); group = (dense step * grp_magic) >> 16
   int gm, gn;   // flm_igemm_bf16.hip: tiles are dealt in groups of gm x gn (the 32 workgroups resident on one XCD)
+  // Position-major layers (fc6) in the fp32 kernel whose tiles span several positions of the map (faces per batch < rows per tile): the
+  // positions are taken in the ORDER posperm gives (byte i of the 64-byte table = the map position at place i), chosen
+  // on the host so that the positions sharing a tile have nearly the same filter taps in bounds -- a tile issues the UNION
+  // of its positions' taps (posmajor_fill_perm below).  posperm_on == 0: places are positions.
+  unsigned long long posperm[8];
+  int posperm_on;
 };
+
+// place -> map position (see IgemmArgs::posperm).  The table sits in scalar registers: eight selects and a shift.
+__device__ __forceinline__ int posmajor_pos(const IgemmArgs& a, int place) {
+  if (!a.posperm_on) return place;
+  unsigned long long w = a.posperm[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) w = (place >> 3) == k ? a.posperm[k] : w;
+  return (int)((w >> ((place & 7) * 8)) & 0xffull);
+}
 
 // Taps of a kh x kw 'same' filter that touch at least one in-bounds pixel for m-tile t in
 // position-major order (positions t*BM/n .. of an h x w map): bit ky*kw+kx.
@@ -72,6 +87,109 @@ __device__ __forceinline__ size_t posmajor_orow(int m, int m_first, int nn0, int
     return (size_t)nn * hw + pos;
   }
   return (size_t)(m % n) * hw + m / n;
+}
+// The same under IgemmArgs::posperm (the fp32 kernel): pos0, pos1 = the MAP positions of m_first's place and of the next
+// place (posmajor_pos); below 32 faces places are positions (posmajor_fill_perm leaves those batches alone).
+__device__ __forceinline__ size_t posmajor_orow(int m, int m_first, int nn0, int pos0, int pos1, int n, int hw) {
+  if (n >= 32) {
+    int nn = nn0 + (m - m_first), pos = pos0;
+    if (nn >= n) {
+      nn -= n;
+      pos = pos1;
+    }
+    return (size_t)nn * hw + pos;
+  }
+  return (size_t)(m % n) * hw + m / n;
+}
+
+// Host side of IgemmArgs::posperm for a launch with rows-per-tile bm.  A tile of a position-major layer issues the UNION
+// of the taps its positions need (zero rows for the positions that do not); when n faces < bm rows, g = bm / n positions
+// share a tile.  Map order pairs (y, x) with (y, x + 1): at fc6 (7x7 'same' on 8x8) and 64 faces the union is 48 taps per
+// 44 used (0.917).  The order chosen here starts from the positions sorted by the RANGES of taps they have in bounds --
+// equal ranges (the middle rows / columns) become neighbours --, from 2 x 2 blocks offset by one, or from the tap counts,
+// each improved by swapping two positions of different groups while that lowers sum(|union| x rows); the best of the
+// three is kept: 0.917 -> 0.955 at g = 2 (the optimum of a perfect matching), 0.786 -> 0.874 at g = 4.  (The bf16 256-row kernel keeps map order: it has no register to spare for the lookups, and its
+// headline batch, 512 faces, has one position per tile anyway.)  Only the ORDER in which tiles take positions changes: every output is the same sum in the
+// same order (the skipped and the not-skipped taps of a row outside its own set are zero products either way), the same
+// bits (tests/test_gpu_forward.py).  Maps of more than 64 positions, n >= bm, n < 32 (split-K territory) or n not dividing bm: left alone.
+void igemm_posperm_enable(int on);
+int igemm_posperm_enabled();
+struct PospermEntry {
+  int h, w, kh, kw, pad, g, on;
+  unsigned long long table[8];
+};
+// (flm_igemm.hip: a small cache behind a mutex -- the search below runs once per layer geometry and group size)
+bool posperm_cache_get(PospermEntry& e);
+void posperm_cache_put(const PospermEntry& e);
+
+inline void posmajor_fill_perm(IgemmArgs& a, int bm) {
+  a.posperm_on = 0;
+  for (int k = 0; k < 8; ++k) a.posperm[k] = 0ull;
+  const int P = a.h * a.w;
+  if (!igemm_posperm_enabled() || P > 64 || P < 2 || a.n < 32 || a.n >= bm || bm % a.n != 0 || a.kh * a.kw > 64) return;
+  const int g = bm / a.n;
+  PospermEntry ent = {a.h, a.w, a.kh, a.kw, a.pad, g, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+  if (!posperm_cache_get(ent)) {
+    unsigned long long mask[64];
+    long long key[3][64];
+    for (int p = 0; p < P; ++p) {
+      const int y = p / a.w, x = p % a.w;
+      const int kx_lo = a.pad - x > 0 ? a.pad - x : 0, kx_hi = a.pad + a.w - 1 - x < a.kw - 1 ? a.pad + a.w - 1 - x : a.kw - 1;
+      const int ky_lo = a.pad - y > 0 ? a.pad - y : 0, ky_hi = a.pad + a.h - 1 - y < a.kh - 1 ? a.pad + a.h - 1 - y : a.kh - 1;
+      unsigned long long m = 0ull;
+      for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) m |= 1ull << (ky * a.kw + kx);
+      mask[p] = m;
+      // three starting orders: by the tap ranges in bounds; by 2 x 2 blocks offset by one (the middle rows / columns, whose
+      // ranges are equal, share a block); by tap count, most first
+      key[0][p] = ((((long long)ky_lo * 64 + ky_hi) * 64 + kx_lo) * 64 + kx_hi) * 64 + p;
+      key[1][p] = ((long long)((y + 1) / 2) * 64 + (x + 1) / 2) * 64 + p;
+      key[2][p] = (long long)(64 - __builtin_popcountll(m)) * (1ll << 40) + key[0][p];
+    }
+    long long best_cost = -1;
+    int best[64];
+    for (int start = 0; start < 3; ++start) {
+      int order[64];
+      for (int p = 0; p < P; ++p) order[p] = p;
+      for (int i = 1; i < P; ++i)  // insertion sort by key
+        for (int j = i; j > 0 && key[start][order[j]] < key[start][order[j - 1]]; --j) {
+          const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+      auto group_cost = [&](int gi) {
+        unsigned long long u = 0ull;
+        int rows = 0;
+        for (int i = gi * g; i < (gi + 1) * g && i < P; ++i) { u |= mask[order[i]]; ++rows; }
+        return (long long)__builtin_popcountll(u) * rows;
+      };
+      for (int sweep = 0; sweep < 64; ++sweep) {  // swap two positions of different groups while that lowers the cost
+        bool better = false;
+        for (int i = 0; i < P; ++i)
+          for (int j = i + 1; j < P; ++j) {
+            if (i / g == j / g) continue;
+            const long long before = group_cost(i / g) + group_cost(j / g);
+            int t = order[i]; order[i] = order[j]; order[j] = t;
+            if (group_cost(i / g) + group_cost(j / g) < before) { better = true; continue; }
+            t = order[i]; order[i] = order[j]; order[j] = t;
+          }
+        if (!better) break;
+      }
+      long long cost = 0;
+      for (int gi = 0; gi * g < P; ++gi) cost += group_cost(gi);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        for (int p = 0; p < P; ++p) best[p] = order[p];
+      }
+    }
+    bool identity = true;
+    for (int i = 0; i < P; ++i) {
+      identity = identity && best[i] == i;
+      ent.table[i >> 3] |= (unsigned long long)best[i] << ((i & 7) * 8);
+    }
+    ent.on = identity ? 0 : 1;
+    posperm_cache_put(ent);
+  }
+  a.posperm_on = ent.on;
+  for (int k = 0; k < 8; ++k) a.posperm[k] = ent.table[k];
 }
 
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }

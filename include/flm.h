@@ -244,6 +244,9 @@ int flm_profile_filter(const char* layer);
  *   "decode_lds_dma"        1 (default): the standalone decode of 68-landmark maps brings its tiles into a three-slot LDS
  *                           ring by buffer_load ... lds (csrc/flm_decode.hip, decode_partial_dma_kernel); 0: one tile of
  *                           register prefetch.  Same results
+ *   "posmajor_order"        1 (default): position-major layers (fc6) at batches smaller than a tile's rows take the map
+ *                           positions that share a tile in an order chosen for their common filter taps
+ *                           (csrc/flm_igemm_args.h, posmajor_fill_perm); 0: map order.  Same bits
  *   "warp_rows"             1 (default): uint8 warps whose destination width is a multiple of 64 run a wave per
  *                           64-pixel row segment, 2 rows per wave (csrc/flm_misc.hip, warp_u8_rows_kernel; 4 or 8: that
  *                           many rows per wave); 0: the pixel-list kernel.  Same bits

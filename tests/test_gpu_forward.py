@@ -154,6 +154,32 @@ def test_fp32_two_level_accumulation_beats_the_single_chain(flm, weights68):
         assert err[1][k] <= 1.05 * e32[k], (k, err[1][k], e32[k])
 
 
+@pytest.mark.parametrize("dtype,n", [("f32", 64), ("f32", 32), ("bf16", 64)])
+def test_fc6_position_order_keeps_the_bits(flm, weights68, dtype, n):
+    """At batches below a tile's rows the positions of fc6's 8x8 map that share a tile are chosen for their common filter
+    taps (IgemmArgs::posperm, csrc/flm_igemm_args.h): only which tile computes a row changes, so fc6's output -- and
+    everything after it -- must be the bits of the map-order launch (knob posmajor_order = 0).  f32 at 64 / 32 faces: two /
+    four positions per 128-row tile; bf16: the 256-row kernel keeps map order (the knob must be a no-op there)."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype=dtype)
+    model.load_weights(weights68)
+    xd = torch.from_numpy(np.random.default_rng(21).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
+    got = {}
+    try:
+        for knob in (0, 1):
+            _lib.check(lib.flm_set_tuning(b"posmajor_order", knob), "set_tuning")
+            lm = model.forward_device(xd, "landmarks", n_points=4).clone()
+            model.forward_device(xd, "probs")
+            torch.cuda.synchronize()
+            got[knob] = (model.intermediate("fc6", n, "probs").clone(), lm)
+    finally:
+        _lib.check(lib.flm_set_tuning(b"posmajor_order", 1), "set_tuning")
+    assert torch.equal(got[0][0], got[1][0]), "fc6"
+    assert torch.equal(got[0][1], got[1][1]), "landmarks"
+
+
 def test_fp32_batches_beyond_2gib_run_in_face_slices(flm, weights68):
     """The fp32 kernel addresses its operands through a 2 GiB buffer window (offsets from 0x80000000 mean zero padding):
     at 512 faces f1 is exactly 2 GiB, so enc2 runs as two launches over whole faces.  Faces are independent rows of
