@@ -104,8 +104,8 @@ def layer_hbm(name, grid):
         # its own: 1.218 GB per batch-64 launch against 1.213 GB algorithmic)
         return None
     if "flm::warp_" in name:
-        # warp_u8_rows_kernel<4> (and warp_u8_kernel<4>) run a thread per 4 output pixels: 64 faces = 1,048,576 threads
-        return "warp_b64" if grid <= 64 * 256 * 256 // 4 else "warp_b512"
+        # warp_u8_rows_kernel<2> runs a thread per 2 output pixels (warp_u8_kernel<4>: per 4): 64 faces <= 2,097,152 threads
+        return "warp_b64" if grid <= 64 * 256 * 256 // 2 else "warp_b512"
     return None
 
 
