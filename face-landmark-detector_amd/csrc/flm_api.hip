@@ -282,10 +282,10 @@ int flm_set_tuning(const char* key, int value) {
     flm::igemm_posperm_enable(value);
     return FLM_OK;
   }
-  if (!strcmp(key, "warp_rows")) {  // uint8 warp, destination width % 64 == 0: a wave per row segment (1; 4 / 8: that many
-                                    // rows per wave instead of 2) or the pixel-list kernel (0)
-    if (value != 0 && value != 1 && value != 4 && value != 8) {
-      set_error("flm_set_tuning: warp_rows must be 0, 1, 4 or 8");
+  if (!strcmp(key, "warp_rows")) {  // uint8 warp, destination width % 64 == 0: a wave per row segment, 2 rows per wave (1;
+                                    // 4: four rows) or the pixel-list kernel (0)
+    if (value != 0 && value != 1 && value != 4) {
+      set_error("flm_set_tuning: warp_rows must be 0, 1 or 4");
       return FLM_ERR_ARG;
     }
     flm::warp_rows_enable(value);

@@ -323,21 +323,24 @@ __global__ __launch_bounds__(256) void warp_u8_kernel(const uint8_t* __restrict_
 static std::atomic<int> g_warp_rows{1};  // A/B knob "warp_rows": same results either way
 void warp_rows_enable(int on) { g_warp_rows.store(on, std::memory_order_relaxed); }
 
-// uint8 sources, destination width a multiple of 64: one wave = 64 consecutive pixels of ONE output row, a workgroup
-// = a 64 x (4 * ROWS) patch of the destination (grid: x segments, row groups, faces).  What the FLM_WARP_VAR ablations
-// of warp_u8_kernel showed at batch 512 (0.163 ms as shipped): 0.092 ms without the stores, 0.090 ms without the
-// gathers, 0.080 ms with neither -- (a) gathers and stores each cost little alone and nearly their sum together: the
+// uint8 sources, destination width a multiple of 64: one wave = 64 consecutive pixels of ROWS consecutive output rows, a
+// workgroup = a strip of 256 columns x ROWS rows (grid: strips across, row groups, faces).  What the FLM_WARP_VAR
+// ablations of warp_u8_kernel showed at batch 512 (0.163 ms as shipped): 0.092 ms without the stores, 0.090 ms without
+// the gathers, 0.080 ms with neither -- (a) gathers and stores each cost little alone and nearly their sum together: the
 // written faces were displacing the source from the L2 (store_stream16 above: 0.163 -> 0.109 ms), and (b) the floor
 // is the kernel's own VALU work, about 150 instructions per pixel with the quarter-rate 32-bit integer multiplies of
 // the pixel -> (row, column) division and of the byte offsets.  Here
 //   - the row and the segment come from the block and wave indices: no division, the row terms are one per wave,
 //   - the byte offsets use 24-bit multiplies (full rate; the launcher checks hs, ws < 2^24),
 //   - the x0 = ws - 1 case is expressed through the weight instead of six selects: the pair starts at xl = ws - 2 and
-//     fx becomes 1, fmaf(1, t1 - t0, t0) = t1 exactly (small integers), the value warp_kernel computes,
-// and the patch keeps a workgroup's gathers inside a few source rows.  Per pixel the arithmetic is warp_kernel<true>'s,
-// the results the same bits (tests/test_gpu_align.py).  Batch 512: 0.109 -> 0.095 ms (0.66 of 8 TB/s by the algorithmic
-// 983,040 B per face), batch 64: 0.0164 -> 0.0140 ms (0.56); random rotations up to 0.6 rad with scales 0.6-1.8: the same
-// time as the pixel-list kernel or better.
+//     fx becomes 1, fmaf(1, t1 - t0, t0) = t1 exactly (small integers), the value warp_kernel computes.
+// Per pixel the arithmetic is warp_kernel<true>'s, the results the same bits (tests/test_gpu_align.py).  Back-to-back
+// launches (bench.py's hbm_kernels protocol; the source stays in the Infinity Cache): 0.109 -> 0.100 ms per 512 faces
+// (0.63 of 8 TB/s by the algorithmic 983,040 B per face), 0.0165 -> 0.0131 per 64.  Inside the step (source cold) 0.150 against
+// 0.153 ms.  The workgroup is a STRIP, not a 64 x 8 patch: equal on near-identity transforms, but on the degenerate
+// transforms the bench pipeline produces (landmarks of random weights fit the template with scale ~0.1 and any
+// rotation: a destination row is a diagonal through the source, most samples clamp to a border COLUMN at varying rows)
+// the patch form took 0.197 ms inside the step where the strip takes 0.164 and the pixel-list kernel 0.162.
 template <int ROWS>
 __global__ __launch_bounds__(256) void warp_u8_rows_kernel(const uint8_t* __restrict__ src, int hs, int ws,
                                                            const float* __restrict__ m, float* __restrict__ dst,
@@ -353,8 +356,10 @@ __global__ __launch_bounds__(256) void warp_u8_rows_kernel(const uint8_t* __rest
   float* dface = dst + (size_t)f * hd * wd * 3;
   __shared__ float stage[4][192];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int xseg = blockIdx.x * 64;
-  const int row0 = (blockIdx.y * 4 + wv) * ROWS;
+  // a workgroup's four waves lie side by side: a strip of 256 columns x ROWS rows
+  const int xseg = (blockIdx.x * 4 + wv) * 64;
+  const int row0 = blockIdx.y * ROWS;
+  if (xseg >= wd) return;  // (wave-uniform; no workgroup barrier below)
   const float xd = (float)(xseg + lane);
   const float xmax = (float)(ws - 1), ymax = (float)(hs - 1);
   const unsigned ws3 = (unsigned)ws * 3u;
@@ -416,17 +421,13 @@ int launch_warp(hipStream_t s, const void* src, int src_is_u8, int n, int hs, in
   }
   if (src_is_u8 && ws >= 2 && (wd & 63) == 0 && hs < (1 << 24) && ws < (1 << 24) &&
       g_warp_rows.load(std::memory_order_relaxed)) {
-    const int rows_knob = g_warp_rows.load(std::memory_order_relaxed);
-    // rows per wave: 2 by default.  Near-identity transforms run the same with 2, 4 or 8 (batch 512: 0.095 ms); the
-    // degenerate ones the bench pipeline produces (landmarks of random weights: scale ~0.07, nearly every sample clamps
-    // to the source's border) cost 0.117 / 0.128 / 0.168 ms with 2 / 4 / 8 (pixel-list kernel: 0.114)
-    const int rows = rows_knob == 1 ? 2 : rows_knob;
-    const int gy = cdiv(hd, 4 * rows);
+    // rows per wave: 2 by default (knob value 4: four)
+    const int rows = g_warp_rows.load(std::memory_order_relaxed) == 4 ? 4 : 2;
+    const int gy = cdiv(hd, rows);
     if (gy <= 65535) {
-      const dim3 grid(wd / 64, gy, n);
+      const dim3 grid(cdiv(wd / 64, 4), gy, n);
       const uint8_t* s8 = static_cast<const uint8_t*>(src);
       if (rows == 4) warp_u8_rows_kernel<4><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
-      else if (rows == 8) warp_u8_rows_kernel<8><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
       else warp_u8_rows_kernel<2><<<grid, 256, 0, s>>>(s8, hs, ws, m, dst, hd, wd);
       FLM_LAUNCH_CHECK("warp_u8_rows_kernel");
       return FLM_OK;

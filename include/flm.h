@@ -248,8 +248,8 @@ int flm_profile_filter(const char* layer);
  *                           positions that share a tile in an order chosen for their common filter taps
  *                           (csrc/flm_igemm_args.h, posmajor_fill_perm); 0: map order.  Same bits
  *   "warp_rows"             1 (default): uint8 warps whose destination width is a multiple of 64 run a wave per
- *                           64-pixel row segment, 2 rows per wave (csrc/flm_misc.hip, warp_u8_rows_kernel; 4 or 8: that
- *                           many rows per wave); 0: the pixel-list kernel.  Same bits
+ *                           64-pixel row segment, 2 rows per wave (csrc/flm_misc.hip, warp_u8_rows_kernel; 4: four rows
+ *                           per wave); 0: the pixel-list kernel.  Same bits
  *   "up3_cand8"             bit 0: the bf16 candidate launch of the last transposed conv runs the 8-wave kernel
  *                           (csrc/flm_convt.hip, up3_cand8_kernel); bit 2: its 4-wave x 2-workgroup shape; default 1;
  *                           0: the generic kernel.  Same keys either way.  Bit 1 (an fp32 form of that kernel) is
