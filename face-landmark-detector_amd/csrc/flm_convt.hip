@@ -694,9 +694,18 @@ namespace cand8 {
 constexpr int MT = 5;
 constexpr int PIECE = 1024;             // one (g, m) fragment tile: 64 lanes x 16 bytes
 constexpr int KEY_CAP = 512;            // keys a wave holds in LDS between flushes
+// FLM_CAND8_LANE (default 1): keys are appended INSIDE the slot stream, each lane to a list of its own (LANE_CAP entries,
+// [entry][lane] in the wave's LDS region) -- a compare, a saved exec mask and a skipped body when no lane hits; no ballot,
+// no mbcnt, no re-test, no branch ladder after the phase.  0: the hit loop (flag bits in the slots, one loop per phase).
+#ifndef FLM_CAND8_LANE
+#define FLM_CAND8_LANE 1
+#endif
+constexpr bool LANE = FLM_CAND8_LANE != 0;
+constexpr int LANE_CAP = FLM_CAND8_LANE > 1 ? FLM_CAND8_LANE : 16;  // keys per lane between flushes; a flush is due when some lane holds LANE_CAP / 2 (macro values > 1: that capacity, for timing the flush)
+constexpr int WAVE_LIST = LANE ? 64 * LANE_CAP : KEY_CAP;
 // WAVES waves per workgroup share a ring of two steps of STEP_G k groups: (8, 9) = one workgroup per CU, 45 KiB steps
 // (bf16: a whole phase); (4, 3) = two workgroups per CU that drift apart, 15 KiB steps, twice the weight traffic
-constexpr size_t lds_bytes(int waves, int step_g) { return 2 * (size_t)step_g * MT * PIECE + (size_t)waves * KEY_CAP * 8; }
+constexpr size_t lds_bytes(int waves, int step_g) { return 2 * (size_t)step_g * MT * PIECE + (size_t)waves * WAVE_LIST * 8; }
 
 template <bool BF>
 struct Cfg {
@@ -777,8 +786,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  unsigned long long* cwave = reinterpret_cast<unsigned long long*>(smem_raw + 2 * SLOT_BYTES) + wave * KEY_CAP;
+  unsigned long long* cwave = reinterpret_cast<unsigned long long*>(smem_raw + 2 * SLOT_BYTES) + wave * WAVE_LIST;
   unsigned wcnt = 0;
+  unsigned lcnt = 0;       // LANE: keys in this lane's list (past LANE_CAP: keys were dropped)
+  unsigned pixq_l[NT];     // LANE: pixel | (4q << 17) of the phase whose products are being tested
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) pixq_l[nt] = 0u;
 
   const int s = a.s;
   const int row0 = blockIdx.y * a.rpw;  // this workgroup walks phase rows row0 .. row0 + rpw - 1: phases t = 0 .. rpw*s - 1
@@ -911,6 +924,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
     wcnt = 0;
   };
 
+  // LANE: the lanes' lists -> the face's global list: an exclusive scan of the counts over the wave (one atomic reserves
+  // the range), every lane copies its own entries.  Due when some lane is half full; a lane that ran out of room in
+  // between has dropped keys: the overflow flag sends the batch through the materialising launch.
+  auto lane_flush = [&]() __attribute__((always_inline)) {
+    const bool over = lcnt > (unsigned)LANE_CAP;
+    if (__any(over) && wlive && lane == 0) atomicOr(&a.cand_cnt[a.n], 1u);
+    const unsigned mine = over ? (unsigned)LANE_CAP : lcnt;
+    unsigned incl = mine;  // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    const unsigned total = __builtin_amdgcn_readlane(incl, 63);
+    if (wlive && total) {
+      unsigned base = 0;
+      if (lane == 0) {
+        base = atomicAdd(&a.cand_cnt[wimg], total);
+        if (base + total > (unsigned)a.cand_cap) atomicOr(&a.cand_cnt[a.n], 1u);
+      }
+      base = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+      for (unsigned i = 0; i < mine; ++i)
+        if (base + i < (unsigned)a.cand_cap) a.cand[(size_t)wimg * a.cand_cap + base + i] = cwave[i * 64 + lane];
+    }
+    lcnt = 0;
+  };
+
   // ---- epilogue state of the phase being finished --------------------------------------------------------------------
   float mx[NT], nmxl[NT], sum[NT], rs[NT];
   unsigned hitmask = 0;
@@ -965,6 +1005,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
       const float inv = BF ? __builtin_amdgcn_rcpf(sq) : 1.0f / sq;
       rs[nt] = ok ? inv : 0.f;
       FLM_PIN(rs[nt]);
+      if constexpr (LANE)
+        pixq_l[nt] = (unsigned)((oy0[nt] + row0 + (bprev >> ls)) * a.wo + ox0[nt] + (bprev & (s - 1))) + ((unsigned)(4 * q) << 17);
     } else if constexpr (K < C::G0) {
       constexpr int nt = (K - C::F0) % NT, i = (K - C::F0) / NT, m = i < 16 ? i >> 2 : 4, e = i < 16 ? i & 3 : 0;
       float v = PV[nt][m][e] * rs[nt];
@@ -978,6 +1020,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
         mk |= __ballot(PV[nt][m][2] >= tq[m].z);
         mk |= __ballot(PV[nt][m][3] >= tq[m].w);
       }
+      if constexpr (LANE) {
+        if (mk) {  // (wave-uniform, about three groups in ten) the hitting lanes append to their own lists
+          const float tv[4] = {tq[m].x, tq[m].y, tq[m].z, tq[m].w};
+#pragma unroll
+          for (int e = 0; e < (m < 4 ? 4 : 1); ++e) {
+            const float pvv = PV[nt][m][e];
+            if (pvv >= tv[e]) {  // (p >= tau > 0: its order bits are its bits with the sign set)
+              const unsigned lo = m < 4 ? pixq_l[nt] + ((unsigned)(16 * m + e) << 17) : pixq_l[nt] + ((unsigned)(64 - 3 * q) << 17);
+              if (lcnt < (unsigned)LANE_CAP)
+                cwave[lcnt * 64 + lane] = ((unsigned long long)(__float_as_uint(pvv) | 0x80000000u) << 32) | lo;
+              ++lcnt;
+            }
+          }
+        }
+        return;
+      }
       hitmask |= mk ? 1u << (nt * MT + m) : 0u;  // (scalar: the products it tests are pinned in their slots)
     }
   };
@@ -989,6 +1047,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
   // when the wave's region is half full); a call that still runs out (more than 256 hits of one wave in one phase: flat
   // maps) drops the excess keys and raises the overflow flag, which sends the batch through the materialising launch.
   auto hit_loop = [&](f32x4(&PV)[NT][MT], int bprev) __attribute__((always_inline)) {
+    if constexpr (LANE) {
+      if (__any(lcnt >= (unsigned)(LANE_CAP / 2))) lane_flush();
+      return;
+    }
     const unsigned hm = __builtin_amdgcn_readfirstlane(hitmask);
     hitmask = 0;
     if (hm == 0) return;
@@ -1144,7 +1206,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void up3_cand8_kernel(ConvTArgs a) {
     static_for<NOPS>([&](auto kc) __attribute__((always_inline)) { epi_op(kc, accB, bprev); });
     hit_loop(accB, bprev);
   }
-  cand_flush();
+  if constexpr (LANE) lane_flush();
+  else cand_flush();
 }
 #undef FLM_PIN
 
