@@ -28,6 +28,7 @@ SOURCES = [
     "flm_score1x1.hip",
     "flm_tail_bf16.hip",
     "flm_convt.hip",
+    "flm_up3_wreg.hip",
     "flm_decode.hip",
     "flm_misc.hip",
     "flm_mobile.hip",

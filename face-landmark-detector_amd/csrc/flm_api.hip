@@ -266,6 +266,15 @@ int flm_set_tuning(const char* key, int value) {
     flm::convt_cand8_rows(value);
     return FLM_OK;
   }
+  if (!strcmp(key, "up3_wreg")) {  // bf16 candidate launch of up3: 1 (default) the weights-in-registers kernel
+                                   // (flm_up3_wreg.hip) where its conditions hold, 0 always the 8-wave kernel.  Same keys
+    if (value < 0 || value > 1) {
+      set_error("flm_set_tuning: up3_wreg must be 0 or 1");
+      return FLM_ERR_ARG;
+    }
+    flm::convt_wreg_enable(value);
+    return FLM_OK;
+  }
   if (!strcmp(key, "bf16_score1x1")) {  // register-resident 1x1 classifier kernel for 256-channel inputs: 0 off, 1 on
     flm::score1x1_enable(value);
     return FLM_OK;
@@ -690,6 +699,8 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     if (rc) return rc;
     ConvTDesc tc = t;
     tc.y = nullptr; tc.epilogue = 3; tc.tau = tau; tc.cand = cand; tc.cand_cnt = cnt; tc.cand_cap = W.cand_cap;
+    // (the probability region is written only by the gated fallback below, after this launch: its scratch until then)
+    tc.scratch = probs; tc.scratch_bytes = sizeof(float) * (size_t)n * W.oh * W.ow * C;
     { ProfScope ps(s, "up3");
     rc = launch_convt(s, tc); }
     if (rc) return rc;

@@ -207,6 +207,8 @@ struct ConvTDesc {
   unsigned* cand_cnt = nullptr;        // [n] + overflow flag at [n]
   int cand_cap = 0;
   const unsigned* gate = nullptr;      // launch is a no-op unless *gate != 0
+  void* scratch = nullptr;             // epilogue 3: memory the launch may use (the bf16 input copy of up3_wreg_kernel), or null
+  size_t scratch_bytes = 0;
 };
 int launch_convt(hipStream_t s, const ConvTDesc& d);
 int convt_candidates_supported(const ConvTGeom& g);
@@ -218,6 +220,7 @@ __host__ __device__ inline int convt_share_layout(const ConvTGeom& g, int s) {
 int convt_sample_slots(const ConvTGeom& g, int hi, int wi, int sub);
 void convt_cand8_enable(int mask);  // A/B knob "up3_cand8"
 void convt_cand8_rows(int rpw);     // A/B knob "up3_cand8_rows"
+void convt_wreg_enable(int on);     // A/B knob "up3_wreg"
 int launch_cand_tau(hipStream_t s, const unsigned* wave_max, int n, int slots, int ld, int l, int n_points, float* tau);
 
 // (activations fp32, or bf16 when `bf16`)

@@ -40,46 +40,10 @@
 // the ordinary decode follow in the stream, gated on that flag, so the result is exact in every case.
 #include <utility>
 
-#include "flm_common.h"
+#include "flm_convt_dev.h"
 
 namespace flm {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct ConvTArgs {
-  const float* x;
-  const void* wf;
-  const float* skip;
-  void* y;
-  int n, hi, wi, ho, wo, s, ldy, epilogue;
-  int C, Cp;
-  int P;  // n*(hi+1)*(wi+1) input positions (one extra row/column: the far taps)
-  int ppf;  // > 0: positions per face padded to a multiple of the workgroup's tile (a workgroup never spans two faces)
-  int ls;   // log2(s): the strides of the reference's decoders are 2, 8 and 32
-  int share;  // packed weights use the shared tile-4 layout (convt_share_layout): 68-class kernels, s % 4 == 0;
-              // the main launches then run the SHARE = true instantiation (template parameter)
-  int nb;   // phases b0 computed per phase row (s, or 1 for the sub-sampled launch)
-  int sub;  // > 0: sampling launch: a workgroup computes `sub` phases chosen from its tile index (not a phase row);
-            // epilogue 1 writes them compactly (pixel index (r, i0, j0) on a sub x (hi+1) x (wi+1) grid), epilogue 4
-            // only the per-wave class maxima: y = unsigned [n][4 * tiles per face][16*MT] float bit patterns
-  const float* tau;           // [n][C] candidate thresholds (epilogue 3)
-  unsigned long long* cand;   // [n][cand_cap] keys: order_bits(p) << 32 | class << 17 | pixel
-  unsigned* cand_cnt;         // [n] entries appended per face; cand_cnt[n] = overflow flag
-  int cand_cap;
-  const unsigned* gate;       // non-null: the launch does nothing unless *gate != 0
-  int rpw;                    // cand8 kernel: phase rows a0 one workgroup walks with the same X fragments (divides s)
-};
-
-// candidate keys one wave can hold in LDS: 128 (fp32) or 256 (bf16, NT = 2) pixels x 68 classes pass through it;
-// the fp32 kernel's 61 KiB weight ring leaves room for 512 per wave if two workgroups are to share a CU
-#define kCandWaveCap (512 * NT)
-constexpr int kMaxSamplePhases = 16;
-
-__device__ __forceinline__ unsigned cand_order_bits(float v) {
-  const unsigned u = __float_as_uint(v);
-  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
-}
 
 // Developer ablations (tools/ab_variants.py builds variants with -DFLM_ABLATE=<mask>; results are wrong, only timings
 // mean anything): 1 no candidate test / stores (part 3), 2 no normalisation (part 2), 4 no max / exp (part 1),
@@ -91,76 +55,6 @@ __device__ __forceinline__ unsigned cand_order_bits(float v) {
 #endif
 constexpr int GCH_F32 = 6, GCH_BF16 = 3;  // k groups per LDS chunk (bf16: smaller chunks, fewer staging registers)
 
-// The library expf for arguments t <= 0: its instruction sequence (t*log2(e) split into a rounded head and an fma'd
-// tail, v_exp_f32 of the fraction, v_ldexp_f32 by the integer part) without the two range tests -- overflow cannot
-// happen, and v_ldexp_f32 underflows by itself.  9 instructions instead of 14 per class and pixel; the same bits as
-// expf for every argument (tools/exp_check.hip: 16.7 M arguments in [-110, 0]) except -103.97 < t < -103.28, where expf
-// cuts to 0 and this returns the smallest denormal, 1.4e-45 (fp32 up3 at batch 64: 1.54 -> 1.515 ms).
-__device__ __forceinline__ float exp_nonpos(float t) {
-  const float ph = t * 0x1.715476p+0f;
-  float pl = __builtin_fmaf(t, 0x1.715476p+0f, -ph);
-  pl = __builtin_fmaf(t, 0x1.4ae0bep-26f, pl);
-  const float e = __builtin_rintf(ph);
-  const float a = (ph - e) + pl;
-  return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
-}
-
-// exp(t) for t <= 0 in the softmax.  fp32 path: the accurate expf above.  bf16 path: v_exp_f32 on
-// t*log2(e) (about 1e-6 relative, far below the bf16 rounding the logits already carry); at 16x the MFMA
-// rate the 20 accurate expf per lane per phase would cost more than the phase's matrix work.
-// x: logit, mx: the pixel's maximum, nmxl = -mx * log2(e).  bf16: one fma + v_exp_f32.
-template <bool BF>
-__device__ __forceinline__ float softmax_exp(float x, float mx, float nmxl) {
-  if constexpr (BF) return __builtin_amdgcn_exp2f(__builtin_fmaf(x, 1.44269504088896340736f, nmxl));
-  else return exp_nonpos(x - mx);
-}
-// max without the quiet-NaN canonicalisation fmaxf() drags in (two extra v_max per call on MFMA results);
-// NaN logits give NaN probabilities either way.
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float max_raw(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// Reductions over the four lane groups q = lane >> 4 (the 16*MT result rows of one pixel sit in lanes r, r+16, r+32,
-// r+48).  v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- and 32-lane rows between two registers in the
-// VALU: with the same value in both, {dst, src} come back as {[x0,x0,x2,x2], [x1,x1,x3,x3]} and {[lo,lo], [hi,hi]},
-// so one swap + one max / add is the xor-16 / xor-32 butterfly step -- no ds_bpermute round trip, no lane-index
-// arithmetic, no lgkmcnt(0) that would also drain the weight-fragment reads in flight.  Same operand pairs as the
-// xor shuffles they replace (a + b in one lane, b + a in its partner): same bits.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float reduce_q_max(float v) {
-  u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = max_raw(__uint_as_float(t.x), __uint_as_float(t.y));
-  t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return max_raw(__uint_as_float(t.x), __uint_as_float(t.y));
-}
-__device__ __forceinline__ float reduce_q_sum(float v) {
-  u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(t.x) + __uint_as_float(t.y);
-  t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(t.x) + __uint_as_float(t.y);
-}
-
-// Maximum over the 16 lanes r = lane & 15 of one lane group (the wave's 16 pixels of one class), in every lane of the
-// group: four DPP steps in the VALU -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror (after
-// the first two a quad is uniform, so the mirrors pair quads and then halves) -- instead of four ds_bpermute shuffles
-// with their lane-index arithmetic and LDS round trips (34 values per wave and sampled phase).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float reduce_r_max(float v) {
-  v = max_raw(v, dpp_mov<0xB1>(v));
-  v = max_raw(v, dpp_mov<0x4E>(v));
-  v = max_raw(v, dpp_mov<0x141>(v));
-  return max_raw(v, dpp_mov<0x140>(v));
-}
 
 // MODE: 0 = epilogues 0/1/2 (maps), 1 = epilogue 3 (top-n candidates), 2 = epilogue 4 (sampling launch: wave maxima)
 template <int MT, int G, bool BF, int NT, int MODE, bool SHARE>
@@ -749,26 +643,6 @@ struct Sched {
   static constexpr EpiSched<BF> k{};
 };
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// LDS-DMA: buffer_load_dwordx4 ... lds writes lane l's 16 bytes to LDS address M0 + 16*l, no VGPR destination.  Inline
-// assembly: through the builtin hipcc would order every later ds_read behind the pending request (vmcnt(0)).
-typedef int dma_srd __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void dma_piece(dma_srd srd, unsigned lds_addr, unsigned voffset, int soffset) {
-  // M0 (the LDS base of the request) is an operand the compiler sets itself ("{m0}"), so it knows the register is
-  // written; the s_nop is the wait state the ISA asks for between a scalar write of M0 and a buffer_load ... lds
-  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-               :
-               : "v"(voffset), "s"(srd), "s"(soffset), "{m0}"(lds_addr)
-               : "memory");
-}
 }  // namespace cand8
 
 template <bool BF, int WAVES, int STEP_G>
@@ -1313,7 +1187,12 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     const int c8 = g_cand8.load(std::memory_order_relaxed);  // bit 0: bf16, bit 1: fp32, bit 2: the 4-wave shape
     // (the 8-wave kernel decodes a phase as (b >> log2 s, b & (s - 1)): s a power of two, checked above)
     if ((d.s & 3) == 0 && d.s >= 4 && (d.s & (d.s - 1)) == 0 && (long long)d.s * d.s * cand8::Cfg<false>::PHASE_BYTES < 0x7fffffffll) {
-      if (d.g.bf16 && (c8 & 1)) return (c8 & 4) ? launch_cand8<true, 4, 3>(st, a) : launch_cand8<true, 8, 9>(st, a);
+      if (d.g.bf16 && (c8 & 1)) {
+        // (knob "up3_wreg", default on: the weights-in-registers kernel where its shape and scratch conditions hold)
+        const int wr = (c8 & 4) ? 0 : launch_up3_wreg(st, a, d.scratch, d.scratch_bytes);
+        if (wr) return wr < 0 ? wr : FLM_OK;
+        return (c8 & 4) ? launch_cand8<true, 4, 3>(st, a) : launch_cand8<true, 8, 9>(st, a);
+      }
       // (bit 1, the fp32 form of that kernel, is retired: the generic kernel's fp32 sum is two-level since round 3 and
       // the 8-wave kernel, a tie in fp32 at best, was not given the same summation tree -- its keys would differ)
     }
