@@ -266,8 +266,8 @@ int flm_set_tuning(const char* key, int value) {
     flm::convt_cand8_rows(value);
     return FLM_OK;
   }
-  if (!strcmp(key, "up3_wreg")) {  // bf16 candidate launch of up3: 1 (default) the weights-in-registers kernel
-                                   // (flm_up3_wreg.hip) where its conditions hold, 0 always the 8-wave kernel.  Same keys
+  if (!strcmp(key, "up3_wreg")) {  // bf16 candidate launch of up3: 1 the weights-in-registers kernel (flm_up3_wreg.hip)
+                                   // where its conditions hold, 0 (default) always the 8-wave kernel.  Same keys
     if (value < 0 || value > 1) {
       set_error("flm_set_tuning: up3_wreg must be 0 or 1");
       return FLM_ERR_ARG;

@@ -1188,7 +1188,7 @@ int launch_convt(hipStream_t st, const ConvTDesc& d) {
     // (the 8-wave kernel decodes a phase as (b >> log2 s, b & (s - 1)): s a power of two, checked above)
     if ((d.s & 3) == 0 && d.s >= 4 && (d.s & (d.s - 1)) == 0 && (long long)d.s * d.s * cand8::Cfg<false>::PHASE_BYTES < 0x7fffffffll) {
       if (d.g.bf16 && (c8 & 1)) {
-        // (knob "up3_wreg", default on: the weights-in-registers kernel where its shape and scratch conditions hold)
+        // (knob "up3_wreg", default off: the weights-in-registers kernel where its shape and scratch conditions hold)
         const int wr = (c8 & 4) ? 0 : launch_up3_wreg(st, a, d.scratch, d.scratch_bytes);
         if (wr) return wr < 0 ? wr : FLM_OK;
         return (c8 & 4) ? launch_cand8<true, 4, 3>(st, a) : launch_cand8<true, 8, 9>(st, a);

@@ -49,6 +49,12 @@ constexpr int BAND_MAX = (LDS_TOTAL - LIST_BYTES - W5_BYTES - TAU_BYTES) / 2 / R
 
 // Developer ablations (-DFLM_WREG_ABLATE=<mask>; wrong results, timings only): 1 no softmax / threshold ops, 2 no MFMAs,
 // 4 no fragment reads, 8 no band fetch, 16 no record test
+// k groups the fragment reads run ahead of the MFMAs (1: rings of two register sets; 2: rings of three -- the same 1.94 ms,
+// and 12 bytes of scratch in the per-band code)
+#ifndef FLM_WREG_AHEAD
+#define FLM_WREG_AHEAD 1
+#endif
+constexpr int AH = FLM_WREG_AHEAD, RING = AH + 1;
 #ifndef FLM_WREG_ABLATE
 #define FLM_WREG_ABLATE 0
 #endif
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
       // under the softmax.  (One group ahead, and a cold start per tile, left every k group waiting on LDS: 1.8 ms, the
       // same with the MFMAs compiled out.)  Reads and waits are by hand; the queue is in order, so "at most four
       // outstanding" after a group's two requests means the group's own pair has landed whatever else was queued between.
-      f32x4 xr[3], w5[3];
+      f32x4 xr[RING], w5[RING];
       auto tile_pos = [&](int t, unsigned& ib, unsigned& jj) __attribute__((always_inline)) {
         const unsigned pl = (unsigned)(16 * t + r);
         ib = __umulhi(pl, a.wi1_magic);
@@ -296,7 +302,10 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
       }
 #define FLM_XRD(SLOT, GG, PA) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[SLOT]) : "v"((PA) + (unsigned)delta[GG]))
 #define FLM_WRD(SLOT, GG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w5[SLOT]) : "v"(w5_lds), "n"((GG) * PIECE))
-      if constexpr (!(FLM_WREG_ABLATE & 4)) { FLM_XRD(0, 0, posaddr); FLM_WRD(0, 0); FLM_XRD(1, 1, posaddr); FLM_WRD(1, 1); }
+      if constexpr (!(FLM_WREG_ABLATE & 4)) {
+        FLM_XRD(0, 0, posaddr); FLM_WRD(0, 0);
+        if constexpr (AH == 2) { FLM_XRD(1, 1, posaddr); FLM_WRD(1, 1); }
+      }
       for (int t = 0; t < ntile; ++t) {
         dma_step();
         // ---- this lane's position of the tile: (row, column), output pixel; the next tile's LDS address ---------------
@@ -319,14 +328,15 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
         cand8::static_for<G>([&](auto gc) __attribute__((always_inline)) {
           constexpr int g = decltype(gc)::value;
           if constexpr (!(FLM_WREG_ABLATE & 4)) {
-            if constexpr (g + 2 < G) {
-              FLM_XRD((g + 2) % 3, g + 2, posaddr); FLM_WRD((g + 2) % 3, g + 2);
-              __builtin_amdgcn_s_waitcnt(0xc47f);    // lgkmcnt(4)
-            } else if (has_next) {
-              FLM_XRD((g + 2) % 3, g + 2 - G, posnext); FLM_WRD((g + 2) % 3, g + 2 - G);
+            // after a group's pair of requests at most 2 AH reads may be outstanding for its own pair to have landed
+            if constexpr (g + AH < G) {
+              FLM_XRD((g + AH) % RING, g + AH, posaddr); FLM_WRD((g + AH) % RING, g + AH);
+              __builtin_amdgcn_s_waitcnt(AH == 2 ? 0xc47f : 0xc27f);
+            } else if (AH == 2 && has_next) {   // (rings of three: 9 groups keep the slots in step from tile to tile)
+              FLM_XRD((g + AH) % RING, g + AH - G, posnext); FLM_WRD((g + AH) % RING, g + AH - G);
               __builtin_amdgcn_s_waitcnt(0xc47f);
-            } else if constexpr (g + 2 == G) {
-              __builtin_amdgcn_s_waitcnt(0xc27f);    // lgkmcnt(2): only group 8's pair may still be out
+            } else if constexpr (g + 2 == G && AH == 2) {
+              __builtin_amdgcn_s_waitcnt(0xc27f);    // only group 8's pair may still be out
             } else {
               __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0)
             }
@@ -334,20 +344,24 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
           if constexpr (!(FLM_WREG_ABLATE & 2)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-              if constexpr (g == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[m]) : "a"(W[g][m]), "v"(xr[g % 3]));
-              else if constexpr (g < GA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(W[g][m]), "v"(xr[g % 3]));
-              else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(W[g][m]), "v"(xr[g % 3]));
+              if constexpr (g == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[m]) : "a"(W[g][m]), "v"(xr[g % RING]));
+              else if constexpr (g < GA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(W[g][m]), "v"(xr[g % RING]));
+              else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(W[g][m]), "v"(xr[g % RING]));
             }
-            if constexpr (g == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[4]) : "v"(w5[g % 3]), "v"(xr[g % 3]));
-            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[4]) : "v"(w5[g % 3]), "v"(xr[g % 3]));
+            if constexpr (g == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[4]) : "v"(w5[g % RING]), "v"(xr[g % RING]));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[4]) : "v"(w5[g % RING]), "v"(xr[g % RING]));
           }
         });
+        // (rings of two: group 0 of the next tile goes where group 8 was, once group 8's MFMAs have been issued)
+        if constexpr (AH == 1 && !(FLM_WREG_ABLATE & 4))
+          if (has_next) { FLM_XRD(0, 0, posnext); FLM_WRD(0, 0); }
         posaddr = posnext;
 #undef FLM_XRD
 #undef FLM_WRD
         // (the compiler cannot see into the MFMAs: the wait states between the last of them and the first vector
         //  instruction that reads a result are ours to leave)
-        asm volatile("s_nop 15" ::: "memory");
+        // (tied to the accumulators: nothing that reads one may be scheduled above it)
+        asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
 
         if constexpr (!(FLM_WREG_ABLATE & 1)) {
           // ---- softmax over the 68 classes of the pixel: this lane's 17 values (classes 16m + 4q + e, and 64 + q from row
@@ -407,7 +421,8 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
   }
 }
 
-static std::atomic<int> g_wreg{1};  // A/B knob "up3_wreg": 1 (default) the bf16 candidate launch of up3 runs this kernel
+static std::atomic<int> g_wreg{0};  // A/B knob "up3_wreg": 1 = the bf16 candidate launch of up3 runs this kernel (default 0: it ties with
+                                    // up3_cand8_kernel, 1.94 against 1.94-1.97 ms per 512 faces, and that one takes every shape)
 void convt_wreg_enable(int on) { g_wreg.store(on, std::memory_order_relaxed); }
 
 // 1: launched; 0: not this kernel's case (the caller takes up3_cand8_kernel); < 0: error

@@ -256,6 +256,10 @@ int flm_profile_filter(const char* layer);
  *                           accepted and ignored: the fp32 path always runs the generic kernel
  *   "up3_cand8_rows"        phase rows one workgroup of that kernel walks with the same input fragments: 0 (default)
  *                           chosen from the batch, else 1, 2, 4 or 8
+ *   "up3_wreg"              1: that launch runs the weights-in-registers kernel instead (csrc/flm_up3_wreg.hip: a wave keeps
+ *                           one phase's weights for its whole life, the input streams past through LDS) where its
+ *                           conditions hold (stride 8, 68 classes; the probability region of the workspace is its
+ *                           scratch); 0 (default).  Same keys
  * The options that change the workspace layout ("landmark_candidates", "candidate_*") are per-call arguments:
  * flm_forward_opts above. */
 int flm_set_tuning(const char* key, int value);

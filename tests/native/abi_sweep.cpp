@@ -117,6 +117,7 @@ int main() {
   CHECK(flm_set_tuning("none", 0) == 0 && flm_set_tuning(nullptr, 0) == FLM_ERR_ARG && flm_set_tuning("nope", 1) == FLM_ERR_ARG);
   CHECK(flm_set_tuning("bf16_group_n", 3) == FLM_ERR_ARG && flm_set_tuning("bf16_group_n", 0) == 0);
   CHECK(flm_set_tuning("up3_cand8_rows", 3) == FLM_ERR_ARG && flm_set_tuning("up3_cand8_rows", 0) == 0);
+  CHECK(flm_set_tuning("up3_wreg", 2) == FLM_ERR_ARG && flm_set_tuning("up3_wreg", 1) == 0 && flm_set_tuning("up3_wreg", 0) == 0);
   CHECK(flm_set_tuning("landmark_candidates", 0) == FLM_ERR_ARG && std::strstr(flm_last_error(), "flm_forward_opts"));
   CHECK(flm_profile_read(0, nullptr, 0, nullptr) == 1 && flm_profile_filter("a-layer-name-that-is-much-too-long-for-the-filter") == FLM_ERR_ARG);
   CHECK(flm_debug_query(nullptr, 0) == -1);

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "face-landmark-detector_amd", "csrc")
-SOURCES = ["flm_igemm.hip", "flm_igemm_bf16.hip", "flm_conv3_halo.hip", "flm_score1x1.hip", "flm_tail_bf16.hip", "flm_convt.hip", "flm_enc1.hip", "flm_decode.hip", "flm_misc.hip", "flm_pack.hip", "flm_mobile.hip"]
+SOURCES = ["flm_igemm.hip", "flm_igemm_bf16.hip", "flm_conv3_halo.hip", "flm_score1x1.hip", "flm_tail_bf16.hip", "flm_convt.hip", "flm_up3_wreg.hip", "flm_enc1.hip", "flm_decode.hip", "flm_misc.hip", "flm_pack.hip", "flm_mobile.hip"]
 
 
 def _file_flags(src):

@@ -75,6 +75,42 @@ def test_eight_wave_kernel_equals_generic_kernel(flm, weights68, dtype):
         _lib.check(lib.flm_set_tuning(b"up3_cand8_rows", 0), "set_tuning")
 
 
+def test_weights_in_registers_kernel_equals_materialised_decode(flm, weights68):
+    """flm_set_tuning "up3_wreg" = 1: up3_wreg_kernel (flm_up3_wreg.hip; bf16 only) against the materialised decode, bit for
+    bit: 256 x 256 (four bands of position rows per face) at 1, 9 and 40 faces (40: more faces than face chunks, so a
+    workgroup walks two), n = 4 and 25; a non-square input whose face fits one band; lists shrunk until they overflow (the
+    gated fallback must still give the exact result)."""
+    from flm_amd import _lib
+    from flm_amd.networks import LANDMARKS_MODELS
+    lib = _lib.load()
+    rng = np.random.default_rng(48)
+    try:
+        _lib.check(lib.flm_set_tuning(b"up3_wreg", 1), "set_tuning")
+        model = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype="bf16")
+        model.load_weights(weights68)
+        for n in (1, 9, 40):
+            xd = torch.from_numpy(rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).cuda()
+            for n_points in (4, 25):
+                ref = _landmarks(model, xd, n_points, 0.0, candidates=False)
+                got = _landmarks(model, xd, n_points, 0.0, candidates=True)
+                assert np.array_equal(got, ref), (n, n_points, np.abs(got - ref).max())
+            _lib.check(lib.flm_set_tuning(b"up3_wreg", 0), "set_tuning")
+            other = _landmarks(model, xd, 25, 0.0, candidates=True)     # the 8-wave kernel on the same batch
+            _lib.check(lib.flm_set_tuning(b"up3_wreg", 1), "set_tuning")
+            assert np.array_equal(other, ref)
+        got = _landmarks(model, xd, 4, 0.0, candidates=True, cap_div=4096)
+        assert np.array_equal(got, _landmarks(model, xd, 4, 0.0, candidates=False))
+        model = LANDMARKS_MODELS["fcn_8"](68, input_height=96, input_width=160, dtype="bf16")
+        model.load_weights(weights68)
+        xd = torch.from_numpy(rng.integers(0, 256, (35, 96, 160, 3), dtype=np.uint8)).cuda()
+        for n_points in (4, 12):
+            ref = _landmarks(model, xd, n_points, 0.0, candidates=False)
+            got = _landmarks(model, xd, n_points, 0.0, candidates=True)
+            assert np.array_equal(got, ref), ("96x160", n_points)
+    finally:
+        _lib.check(lib.flm_set_tuning(b"up3_wreg", 0), "set_tuning")
+
+
 def test_candidate_overflow_falls_back(flm, weights68):
     """Lists 1/4096 of their size overflow in every face: the gated materialising launch must take over."""
     from flm_amd.networks import LANDMARKS_MODELS
