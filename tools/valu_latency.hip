@@ -9,6 +9,9 @@ constexpr int ITERS = 2048, UNROLL = 32;
 template <int MODE>
 __global__ void k(float* out, float seed) {
   float a = seed + threadIdx.x, b = seed * 2.f, c = seed * 3.f, d = seed * 4.f;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 pa = {a, b}, pb = {b, c}, pc = {c, d}, pd = {d, a}, pe = {seed, seed};
+  unsigned sc = blockIdx.x;
   for (int i = 0; i < ITERS; ++i) {
 #pragma unroll
     for (int u = 0; u < UNROLL / 4; ++u) {
@@ -26,12 +29,24 @@ __global__ void k(float* out, float seed) {
         asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %0, %0\n v_exp_f32 %0, %0\n v_exp_f32 %0, %0" : "+v"(a));
       } else if constexpr (MODE == 6) {  // independent exps
         asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %4\n v_exp_f32 %2, %4\n v_exp_f32 %3, %4" : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(seed));
+      } else if constexpr (MODE == 8) {  // packed fma, four independent register pairs
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd) : "v"(pe));
+      } else if constexpr (MODE == 9) {  // packed mul
+        asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd) : "v"(pe));
+      } else if constexpr (MODE == 10) {  // v_sub_u32 + v_max3_i32 mix (the record test)
+        asm volatile("v_sub_u32 %0, %2, %3\n v_sub_u32 %1, %3, %2\n v_max3_i32 %2, %2, %0, %1\n v_sub_u32 %0, %2, %3" : "+v"(a), "+v"(b), "+v"(c) : "v"(d));
+      } else if constexpr (MODE == 11) {  // s_nop 0 between adds
+        asm volatile("v_add_f32 %0, %0, %1\n s_nop 0\n v_add_f32 %0, %0, %1\n s_nop 0" : "+v"(a) : "v"(b));
+      } else if constexpr (MODE == 12) {  // scalar instructions only
+        asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(sc));
+      } else if constexpr (MODE == 13) {  // vector / scalar alternating (independent)
+        asm volatile("v_add_f32 %0, %0, %2\n s_add_u32 %1, %1, 1\n v_add_f32 %0, %0, %2\n s_add_u32 %1, %1, 1" : "+v"(a), "+s"(sc) : "v"(b));
       } else if constexpr (MODE == 7) {  // exp then an independent add, alternating
         asm volatile("v_exp_f32 %0, %2\n v_add_f32 %1, %1, %2\n v_exp_f32 %0, %2\n v_add_f32 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(c));
       }
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + pa[0] + pb[1] + pc[0] + pd[1] + (float)sc;
 }
 
 template <int MODE>
@@ -54,7 +69,7 @@ void run(const char* what, int threads) {
 }
 
 int main() {
-  for (int t : {256, 512}) {
+  for (int t : {256, 512, 1024}) {
     run<0>("dependent v_add_f32 chain", t);
     run<1>("four independent v_add_f32 chains", t);
     run<3>("two dependent v_add_f32 chains interleaved", t);
@@ -63,6 +78,12 @@ int main() {
     run<5>("dependent v_exp_f32 chain", t);
     run<6>("independent v_exp_f32", t);
     run<7>("v_exp_f32 / independent v_add_f32 alternating", t);
+    run<8>("independent v_pk_fma_f32 (two values each)", t);
+    run<9>("independent v_pk_mul_f32 (two values each)", t);
+    run<10>("v_sub_u32 x3 + v_max3_i32", t);
+    run<11>("v_add_f32 / s_nop 0 alternating (per instruction, nops counted)", t);
+    run<12>("s_add_u32 chain", t);
+    run<13>("v_add_f32 / s_add_u32 alternating", t);
   }
   return 0;
 }
