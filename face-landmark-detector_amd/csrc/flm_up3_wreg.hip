@@ -193,7 +193,7 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
     if (dma_round < a.ndma) {
       const int off = dma_round * ROUND;
       if (!(FLM_WREG_ABLATE & 8)) {
-        stage = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff, dma_src + off, 0));
+        stage = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff, __builtin_amdgcn_readfirstlane(dma_src + off), 0));  // (said to be uniform: hipcc built a waterfall loop round the load)
         stage_dst = lds0 + (unsigned)(dma_dst + off) + voff;
       }
       ++dma_round;
@@ -294,12 +294,9 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
         jj = pl - ib * (unsigned)a.wi1;
         return pl < (unsigned)npos;
       };
-      unsigned posaddr;
-      {
-        unsigned ib, jj;
-        const bool valid = tile_pos(0, ib, jj);
-        posaddr = valid ? buf + ib * (unsigned)a.pitch + jj * (unsigned)POSB : buf;
-      }
+      unsigned posaddr, ib, jj;   // the current tile's LDS address and (row, column), carried from the tile before
+      bool valid = tile_pos(0, ib, jj);
+      posaddr = valid ? buf + ib * (unsigned)a.pitch + jj * (unsigned)POSB : buf;
 #define FLM_XRD(SLOT, GG, PA) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[SLOT]) : "v"((PA) + (unsigned)delta[GG]))
 #define FLM_WRD(SLOT, GG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w5[SLOT]) : "v"(w5_lds), "n"((GG) * PIECE))
       if constexpr (!(FLM_WREG_ABLATE & 4)) {
@@ -309,18 +306,13 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
       for (int t = 0; t < ntile; ++t) {
         dma_step();
         // ---- this lane's position of the tile: (row, column), output pixel; the next tile's LDS address ---------------
-        unsigned ib, jj;
-        const bool valid = tile_pos(t, ib, jj);
         const unsigned oy = 8u * ((unsigned)(b * a.rb) + ib) + (unsigned)a0, ox = 8u * jj + (unsigned)b0;
         const bool okpix = valid && oy < (unsigned)a.ho && ox < (unsigned)a.wo;
         const unsigned pixq = oy * (unsigned)a.wo + ox + ((unsigned)(4 * q) << 17);
         const bool has_next = t + 1 < ntile;
         unsigned posnext;
-        {
-          unsigned ibn, jjn;
-          const bool vn = tile_pos(t + 1, ibn, jjn) && has_next;
-          posnext = vn ? buf + ibn * (unsigned)a.pitch + jjn * (unsigned)POSB : buf;
-        }
+        valid = tile_pos(t + 1, ib, jj) && has_next;   // (from here on: the next tile's)
+        posnext = valid ? buf + ib * (unsigned)a.pitch + jj * (unsigned)POSB : buf;
 
         // ---- 45 MFMAs.  The weight operand of the common tiles is named as an accumulation register (k groups below GA);
         //      the first MFMA of an accumulator takes a zero srcC. -------------------------------------------------------
@@ -376,8 +368,17 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
           mx = max_raw(mx, v[16]);
           mx = reduce_q_max(mx);
           const float nmxl = -mx * 1.44269504088896340736f;
+          // (exponent arguments two at a time, v_pk_fma_f32: the same fma per value; an instruction of any kind costs a wave
+          //  ~2.3 ns, tools/valu_latency.hip)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 l2 = {1.44269504088896340736f, 1.44269504088896340736f}, n2 = {nmxl, nmxl};
 #pragma unroll
-          for (int i = 0; i < 17; ++i) v[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[i], 1.44269504088896340736f, nmxl));
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 t2 = __builtin_elementwise_fma((f32x2){v[i], v[i + 1]}, l2, n2);
+            v[i] = __builtin_amdgcn_exp2f(t2[0]);
+            v[i + 1] = __builtin_amdgcn_exp2f(t2[1]);
+          }
+          v[16] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[16], 1.44269504088896340736f, nmxl));
           float sum = 0.f + v[0];
 #pragma unroll
           for (int i = 1; i < 17; ++i) sum += v[i];
@@ -386,25 +387,25 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
 #pragma unroll
           for (int i = 0; i < 17; ++i) v[i] *= rs;
           if constexpr (!(FLM_WREG_ABLATE & 16)) {
-            // ---- any p >= tau?  d = bits(p) - bits(tau) (p, tau > 0: the integer order is the float order); the lanes
-            //      whose largest d is >= 0 store a record -----------------------------------------------------------------
+            // ---- any p >= tau?  The lanes whose largest p - tau is >= 0 store a record ------------------------------------
             typedef __attribute__((address_space(3))) const f32x4 lds_f32x4r;
             typedef __attribute__((address_space(3))) const float lds_f32r;
             f32x4 tq4[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) tq4[m] = *reinterpret_cast<lds_f32x4r*>(tau_q + 64 * m);
             const float tq16 = *reinterpret_cast<lds_f32r*>(tau_q + 256 - 12 * q);  // class 64 + q
-            int hmax = (int)(__float_as_uint(v[16]) - __float_as_uint(tq16));
+            // (d = p - tau in float, two at a time: the sign of a float difference is exact, and a NaN p never wins a v_max3)
+            float hmax = v[16] - tq16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int d = (int)(__float_as_uint(v[i]) - __float_as_uint(tq4[i >> 2][i & 3]));
-              hmax = hmax > d ? hmax : d;
+            for (int i = 0; i < 16; i += 2) {
+              const f32x2 d2 = (f32x2){v[i], v[i + 1]} - (f32x2){tq4[i >> 2][i & 3], tq4[i >> 2][(i & 3) + 1]};
+              hmax = max3_raw(hmax, d2[0], d2[1]);
             }
-            const unsigned long long mk = __ballot(hmax >= 0);
+            const unsigned long long mk = __ballot(hmax >= 0.f);
             if (mk) {
               const unsigned add = (unsigned)__builtin_popcountll(mk);
               if (wcnt + add > (unsigned)REC_CAP) rec_flush(face, tau_q - 16u * q);
-              if (hmax >= 0) {
+              if (hmax >= 0.f) {
                 const unsigned slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
                 const unsigned ra = rec0 + slot * REC_BYTES;
 #pragma unroll
