@@ -100,6 +100,16 @@ def test_weights_in_registers_kernel_equals_materialised_decode(flm, weights68):
             assert np.array_equal(other, ref)
         got = _landmarks(model, xd, 4, 0.0, candidates=True, cap_div=4096)
         assert np.array_equal(got, _landmarks(model, xd, 4, 0.0, candidates=False))
+        # flat maps (zero upsampling kernels: p = 1/68 everywhere, every lane of every tile stores a record, every list
+        # overflows): the record lists flush once per tile and the gated fallback must give the tie rule's result
+        wz = {k: np.array(v, copy=True) for k, v in weights68.items()}
+        for k in list(wz):
+            if k.startswith(("up3", "up4", "up5")):
+                wz[k][...] = 0
+        flat = LANDMARKS_MODELS["fcn_8"](68, input_height=256, input_width=256, dtype="bf16")
+        flat.load_weights(wz)
+        xd = torch.from_numpy(rng.integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)).cuda()
+        assert np.array_equal(_landmarks(flat, xd, 4, 0.0, candidates=True), _landmarks(flat, xd, 4, 0.0, candidates=False))
         model = LANDMARKS_MODELS["fcn_8"](68, input_height=96, input_width=160, dtype="bf16")
         model.load_weights(weights68)
         xd = torch.from_numpy(rng.integers(0, 256, (35, 96, 160, 3), dtype=np.uint8)).cuda()
