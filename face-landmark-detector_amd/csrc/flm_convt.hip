@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
   unsigned wcnt = 0;
   // sampling launch (epilogue 4): per-wave class maxima as float bit patterns (p >= 0: unsigned order = float order)
   unsigned* wmax = reinterpret_cast<unsigned*>(smem_raw + sizeof(float4) * 2 * CHUNK_F4 + X4_BYTES +
-                                               (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0)) +
+                                               (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 4 * 16 * MT : 0)) +
                    wave * kMaxSamplePhases * 16 * MT;  // [phase of the tile's list][result row]
   if (SAMPLE)
     for (int c = lane; c < a.sub * 16 * MT; c += 64) wmax[c] = 0u;
@@ -129,14 +129,17 @@ __global__ __launch_bounds__(256, (!BF && MT >= 5 && G >= 20) ? 1 : 2) void conv
       img[nt] = pp / (wi1 * hi1);
     }
   }
-  // candidate mode: thresholds of this workgroup's face for the 4*MT classes of this lane (16m + 4q + e)
-  const int wg_img = CAND ? (blockIdx.x * 64 * NT) / (a.ppf > 0 ? a.ppf : 1) : 0;
+  // candidate mode: thresholds of this WAVE's face for the 4*MT classes of a lane (16m + 4q + e).  Faces are padded at
+  // wave granularity there (16*NT positions: 1,104 of them per 256 x 256 face in fp32 where whole workgroups took 1,152,
+  // 5.5 % of the launch's positions), so the four waves of a workgroup may belong to two faces: thresholds and flush per wave
+  const int wg_img = CAND ? __builtin_amdgcn_readfirstlane(((blockIdx.x * 4 + wave) * 16 * NT) / (a.ppf > 0 ? a.ppf : 1)) : 0;
   if (CAND) {
-    // thresholds of this workgroup's face, clamped to FLT_MIN so that p >= tau implies p > 0 (zero weights cannot
-    // move a centroid; a class left with fewer than n keys is caught by cand_merge_kernel)
-    if (tid < 16 * MT) {  // indexed by result row: class of row p
-      const int cls = (C68 && tid >= 64) ? (((tid & 3) == 0) ? 64 + ((tid - 64) >> 2) : a.C) : tid;
-      tau_s[tid] = (cls < a.C && wg_img < a.n) ? fmaxf(a.tau[(size_t)wg_img * a.C + cls], 1.17549435e-38f) : 3.402823466e38f;
+    tau_s += wave * 16 * MT;
+    // thresholds clamped to FLT_MIN so that p >= tau implies p > 0 (zero weights cannot move a centroid; a class left
+    // with fewer than n keys is caught by cand_merge_kernel)
+    for (int c = lane; c < 16 * MT; c += 64) {  // indexed by result row: class of row p
+      const int cls = (C68 && c >= 64) ? (((c & 3) == 0) ? 64 + ((c - 64) >> 2) : a.C) : c;
+      tau_s[c] = (cls < a.C && wg_img < a.n) ? fmaxf(a.tau[(size_t)wg_img * a.C + cls], 1.17549435e-38f) : 3.402823466e38f;
     }
   }
 
@@ -1110,7 +1113,7 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
   constexpr bool CAND = MODE == 1;
   constexpr int GCH = BF ? GCH_BF16 : GCH_F32;
   constexpr size_t lds = sizeof(float4) * 2 * GCH * MT * 64 + ((BF && MT == 5 && G == 9) ? sizeof(float4) * 4 * 2 * NT * 64 : 0) +
-                         (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 16 * MT : 0) +
+                         (CAND ? sizeof(unsigned long long) * 4 * kCandWaveCap + sizeof(float) * 4 * 16 * MT : 0) +
                          (MODE == 2 ? sizeof(unsigned) * 4 * kMaxSamplePhases * 16 * MT : 0);
   // two workgroups per CU (160 KiB of LDS) is what the 68-class kernels are scheduled for: a key buffer that pushed the
   // fp32 candidate kernel to 94 KiB cost 22 % of up3
@@ -1118,7 +1121,10 @@ static int launch_t(hipStream_t st, ConvTArgs a) {
   static FuncAttrOnce attr;
   FLM_FUNC_ATTR_ONCE(attr, (&convt_kernel<MT, G, BF, NT, MODE, SHARE>), lds);
   int xblocks = cdiv(a.P, 64 * NT);
-  if (a.ppf > 0) {  // per-face padding: a workgroup's 64*NT positions belong to one face
+  if (a.ppf > 0 && CAND) {  // per-face padding at wave granularity: a WAVE's 16*NT positions belong to one face
+    a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 16 * NT) * 16 * NT;
+    xblocks = (int)(((long long)a.n * a.ppf + 64 * NT - 1) / (64 * NT));
+  } else if (a.ppf > 0) {   // (sampling launch) a workgroup's 64*NT positions belong to one face
     a.ppf = cdiv((a.hi + 1) * (a.wi + 1), 64 * NT) * 64 * NT;
     xblocks = a.n * (a.ppf / (64 * NT));
   }
