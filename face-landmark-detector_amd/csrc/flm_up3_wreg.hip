@@ -7,21 +7,22 @@
 // barrier per phase for all eight waves, every wave reading the whole ring step), and round 3's ablations priced the
 // requests at 0.4 ms and the wait + barrier at 0.2 ms of its 1.9 ms.  Here the roles are swapped:
 //   * a wave owns ONE phase (a0, b0) for its whole life: the 36 fragment pieces of the phase's four common class tiles
-//     (9 k groups x 4, 144 accumulation registers, which the matrix instructions read where they lie) are loaded once;
+//     (9 k groups x 4: 128 accumulation registers, which the matrix instructions read where they lie, + 16 ordinary
+//     ones: with two waves per SIMD hipcc splits the 256 registers evenly between the two files) are loaded once;
 //     the eight waves of a workgroup are the eight phases of two leader groups, and a group's shared fifth tile (classes
 //     64..67 of its four phases on rows 4q' + j, flm_pack.hip) sits in LDS, 9 KiB per group: a wave multiplies it like
 //     the others and keeps register j of the result -- the bits up3_cand8_kernel gets;
 //   * the input, converted ONCE per launch to bf16 with its zero ring ([face][hi+2][wi+2][72], up3_xpack_kernel),
 //     streams through LDS in bands of position rows (two buffers; the next band arrives one 16-byte piece per lane and
 //     tile while the current one is multiplied); a tile's X fragments are 9 ds_read_b128 from the band through a ring
-//     of three registers sets, two k groups ahead of the MFMAs;
+//     of two register sets, one k group ahead of the MFMAs (FLM_WREG_AHEAD);
 //   * two waves per SIMD and NO software pipeline inside a wave: a tile is 45 MFMAs, then its softmax / threshold
 //     test on the results in place; the matrix work of one wave runs under the vector work of the other.  (The first
 //     form -- one wave per SIMD with all 45 pieces in 180 registers and the epilogue of tile t-1 dealt over the MFMA
-//     slots of tile t -- measured 2.8 ms: a lone wave issues one instruction per ~6 cycles whatever its kind, and its
-//     MFMAs and vector instructions simply added up, 1.0 + 1.5 + 0.3 ms.)
+//     slots of tile t -- measured 2.8 ms: a lone wave issues one instruction per 4 cycles whatever its kind (tools/valu_latency.hip),
+//     and its MFMAs and vector instructions simply added up, 1.0 + 1.5 + 0.3 ms.)
 //   * one barrier per BAND, not per phase; a lane with some p >= tau among its 17 values stores them as a RECORD in
-//     its wave's LDS list (one test per tile: the maximum of bits(p) - bits(tau)); the re-test against the thresholds
+//     its wave's LDS list (one test per tile: the maximum of p - tau); the re-test against the thresholds
 //     and the keys happen when the list is flushed, a few times per face.
 // Arithmetic per value is the generic kernel's, operation by operation (same MFMA order over k, same max / exp / sum
 // order / reciprocal / product), so the keys carry the bits of its materialising and sampling launches: thresholds stay
@@ -47,14 +48,14 @@ constexpr int TAU_BYTES = 2 * 80 * 4;    // the clamped thresholds of two faces 
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int BAND_MAX = (LDS_TOTAL - LIST_BYTES - W5_BYTES - TAU_BYTES) / 2 / ROUND * ROUND;  // one band buffer, whole rounds
 
-// Developer ablations (-DFLM_WREG_ABLATE=<mask>; wrong results, timings only): 1 no softmax / threshold ops, 2 no MFMAs,
-// 4 no fragment reads, 8 no band fetch, 16 no record test
 // k groups the fragment reads run ahead of the MFMAs (1: rings of two register sets; 2: rings of three -- the same 1.94 ms,
 // and 12 bytes of scratch in the per-band code)
 #ifndef FLM_WREG_AHEAD
 #define FLM_WREG_AHEAD 1
 #endif
 constexpr int AH = FLM_WREG_AHEAD, RING = AH + 1;
+// Developer ablations (-DFLM_WREG_ABLATE=<mask>; wrong results, timings only): 1 no softmax / threshold ops, 2 no MFMAs,
+// 4 no fragment reads, 8 no band fetch, 16 no record test
 #ifndef FLM_WREG_ABLATE
 #define FLM_WREG_ABLATE 0
 #endif
@@ -282,11 +283,11 @@ __global__ __launch_bounds__(wreg::WAVES * 64, 2) void up3_wreg_kernel(wreg::Arg
       const int npos = rows * a.wi1;
       const int ntile = (npos + 15) >> 4;
       const unsigned buf = lds0 + (unsigned)((unit & 1) * a.band_stride + a.pitch + POSB);
-      // X fragments and the fifth tile's pieces go through rings of three register sets, read TWO k groups ahead of the
-      // MFMAs that use them, across tiles: groups 7 and 8 of a tile request groups 0 and 1 of the next one, so those land
-      // under the softmax.  (One group ahead, and a cold start per tile, left every k group waiting on LDS: 1.8 ms, the
-      // same with the MFMAs compiled out.)  Reads and waits are by hand; the queue is in order, so "at most four
-      // outstanding" after a group's two requests means the group's own pair has landed whatever else was queued between.
+      // X fragments and the fifth tile's pieces go through rings of RING register sets, read AH k groups ahead of the MFMAs
+      // that use them, across tiles: the last groups of a tile request the first of the next one, so those land under
+      // the softmax (AH = 1: once group 8's MFMAs have been issued, into its set; AH = 2 measured the same).  Reads and
+      // waits are by hand; the queue is in order, so "at most 2 AH outstanding" after a group's two requests means the
+      // group's own pair has landed whatever else was queued between.
       f32x4 xr[RING], w5[RING];
       auto tile_pos = [&](int t, unsigned& ib, unsigned& jj) __attribute__((always_inline)) {
         const unsigned pl = (unsigned)(16 * t + r);
