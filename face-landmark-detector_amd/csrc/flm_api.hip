@@ -79,9 +79,12 @@ static bool resolve_opts(const flm_forward_opts* o, CandOpts* c) {
 // More sampled phases cost 1/64 of up3 each and tighten the threshold: the key lists shrink about in proportion.  At
 // n = 4 the lists are short anyway (4 phases: 8-10 k keys per face); at n >= 16 their merge costs more than the extra
 // phases (batch 512 bf16, n = 25: 12.1 ms with 4 phases, 11.5 with 8; tools/ab_sub.py).
-static int cand_sub_for(const CandOpts& c, int n_points) {
+// In fp32 a sampled phase costs sixteen times the matrix time it costs in bf16 while a key costs the same: at n <= 8 two
+// phases do (batch 64, n = 4: 8.335 / 8.318 / 8.29 ms per step with 4 / 3 / 2 phases, 9.6 k / 13.4 k / 20.2 k keys per face of
+// the 69.6 k the lists hold; bf16 batch 512: 7.76-7.93 / 7.84-8.15 / 8.01-8.03).
+static int cand_sub_for(const CandOpts& c, int n_points, bool bf16) {
   if (c.sub > 0) return c.sub;
-  return n_points <= 8 ? 4 : (n_points <= 15 ? 6 : 8);
+  return n_points <= 8 ? (bf16 ? 4 : 2) : (n_points <= 15 ? 6 : 8);
 }
 static bool landmark_candidates_enabled(const CandOpts& c, const ConvTGeom& g, int fcn32, int decode_mode, int n_points,
                                         int oh, int ow) {
@@ -149,7 +152,7 @@ Fcn8Ws fcn8_ws_layout(int n, int h, int w, int C, int dtype, int out_mode, int d
     W.decode = take(cur, decode_ws_bytes(n, W.oh, W.ow, C, decode_mode, n_points));
     if (landmark_candidates_enabled(co, g, A.fcn32, decode_mode, n_points, W.oh, W.ow)) {
       const int h3 = h / 8, w3 = w / 8;
-      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, cand_sub_for(co, n_points)) * 16 * g.MT);  // sampled maxima
+      W.sub = take(cur, sizeof(unsigned) * (size_t)n * convt_sample_slots(g, h3, w3, cand_sub_for(co, n_points, g.bf16 != 0)) * 16 * g.MT);  // sampled maxima
       W.tau = take(cur, sizeof(float) * (size_t)n * C);
       // expected keys per class: the n-th of 1/64 of the pixels ranks about 64*n-th overall; x4 head room
       // (never below one 64-key block: a huge cap_div then still takes the documented overflow fallback instead of
@@ -689,12 +692,12 @@ static int forward_impl(flm_stream_t stream, const void* packed_dev, const void*
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + W.cand);
     FLM_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned) * ((size_t)n + 1), s));
     ConvTDesc ts = t;
-    ts.y = sub; ts.epilogue = 4; ts.sub = cand_sub_for(co, n_points);
+    ts.y = sub; ts.epilogue = 4; ts.sub = cand_sub_for(co, n_points, L.g.bf16 != 0);
     { ProfScope ps(s, "up3_sub");
     rc = launch_convt(s, ts); }
     if (rc) return rc;
     { ProfScope ps(s, "tau");
-    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, cand_sub_for(co, n_points)), 16 * L.g.MT, C,
+    rc = launch_cand_tau(s, reinterpret_cast<const unsigned*>(sub), n, convt_sample_slots(L.g, t.hi, t.wi, cand_sub_for(co, n_points, L.g.bf16 != 0)), 16 * L.g.MT, C,
                          n_points, tau); }
     if (rc) return rc;
     ConvTDesc tc = t;

@@ -185,8 +185,8 @@ int flm_fcn_forward(flm_stream_t stream, int arch, const void* packed_dev, const
  *                         from candidate keys emitted by the last transposed conv instead of materialising the
  *                         [N,H'*W',C] probabilities (bit-identical landmarks, gated fallback); 0: always materialise
  *                         and decode (the decode of utils/metrics.py:102-109 on model.predict's output, literally)
- *   candidate_sub_phases  phases per tile in that path's sampling launch (1..16; 0 = by n_points: 4 up to n = 8, 6 up
- *                         to 15, 8 beyond)
+ *   candidate_sub_phases  phases per tile in that path's sampling launch (1..16; 0 = by n_points: 4 up to n = 8 (fp32: 2),
+ *                         6 up to 15, 8 beyond)
  *   candidate_cap_div     shrink the candidate lists by this factor (>= 1; tests of the overflow fallback) */
 typedef struct flm_forward_opts {
   uint32_t struct_size;
